@@ -1,0 +1,176 @@
+/*
+ * mil.h — C ABI of libmil.so, the MI355X-native lighting + tonemap pass for
+ * dobrakmato/renderer's deferred path.
+ *
+ * The reference has no plugin / operator / FFI interface for this path: the pass
+ * is the inline `draw_indexed` at renderer/src/render/mod.rs:201-216 (lighting)
+ * and :297-309 (tonemap).  The boundary below is therefore defined from that
+ * draw's Vulkan bindings; every struct is byte-identical to what the reference
+ * binds, so the Rust side can pass `&FrameMatrixData` / `&[DirectionalLight; N]`
+ * unchanged (binding stub: INTEGRATION.md).  All paths are relative to
+ * /root/reference/.
+ *
+ * Conventions: every image pointer is DEVICE memory owned by the caller; every
+ * uniform struct / light array pointer is HOST memory, copied during the call
+ * (mirrors the reference's per-frame CpuBufferPool ring, render/pools.rs:42-57).
+ * Calls enqueue work on `stream` (a hipStream_t, 0 = default stream) and return;
+ * no call allocates after mil_create.  One context = one thread at a time.
+ * All functions return 0 on success or a negative mil_status; nothing aborts.
+ */
+#ifndef MIL_H
+#define MIL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIL_VERSION 1
+#define MIL_MAX_DIR_LIGHTS 100u /* MAX_LIGHTS, renderer/shaders/inc_structs.glsl:1; pool render/pbr/mod.rs:36 */
+#define MIL_TILE 16u            /* screen tile edge of the culled path */
+
+typedef enum mil_status {
+    MIL_OK = 0,
+    MIL_ERR_BAD_ARG = -1,         /* null pointer, zero size, pitch < width, bad enum */
+    MIL_ERR_TOO_MANY_LIGHTS = -2, /* the reference panics here (render/mod.rs:197-199); we return */
+    MIL_ERR_HIP = -3,             /* a HIP runtime call failed; mil_last_hip_error() has the code */
+    MIL_ERR_NO_DEVICE = -4,
+    MIL_ERR_CAPACITY = -5         /* more point lights than the context was created for */
+} mil_status;
+
+/* FrameMatrixData — renderer/src/render/ubo.rs:28-41; GLSL block
+ * shaders/fs_deferred_lighting.glsl:16-22.  std140, 272 bytes, mat4 column-major
+ * (cgmath Matrix4 = 4 column vectors).  Filled per frame at render/mod.rs:96-104. */
+typedef struct mil_frame_matrix_data {
+    float view[16];
+    float projection[16];
+    float inv_projection[16];
+    float inv_view[16];
+    float camera_position[3];
+    float _pad;
+} mil_frame_matrix_data;
+
+/* DirectionalLight — render/ubo.rs:54-63; shaders/inc_structs.glsl:12-16.
+ * std140 array stride 32.  `direction` points from the pixel toward the light
+ * and is NOT normalised by the shader (the CPU does, main.rs:82,87). */
+typedef struct mil_directional_light {
+    float direction[3];
+    float intensity;
+    float color[3];
+    float _pad;
+} mil_directional_light;
+
+/* Push constants of the lighting draw — shaders/fs_deferred_lighting.glsl:24-27,
+ * set at render/mod.rs:211-214.  12 bytes.  `resolution` is the FULL framebuffer
+ * size even when a strip is shaded. */
+typedef struct mil_push_constants {
+    float resolution[2];
+    uint32_t light_count;
+} mil_push_constants;
+
+/* The four input attachments of the lighting subpass, in binding order
+ * (shaders/fs_deferred_lighting.glsl:5-8; formats render/pbr/mod.rs:150-160;
+ * encoding written by shaders/fs_deferred_geometry.glsl:47-49).  One u32/f32 per
+ * pixel per plane, row 0 = top.  A strip of a larger frame sets y_offset to the
+ * global row of its first row; PositionFromDepth uses global coordinates. */
+typedef struct mil_gbuffer {
+    const uint32_t *normal_l_model;     /* A2B10G10R10_UNORM_PACK32: R[9:0] G[19:10] B[29:20] A[31:30] */
+    const uint32_t *albedo_occlusion;   /* R8G8B8A8_UNORM: albedo rgb, occlusion a */
+    const uint32_t *roughness_metallic; /* R8G8B8A8_UNORM: roughness r, metallic g */
+    const float *depth;                 /* D32_SFLOAT, viewport depth range 0..1, cleared to 1.0 */
+    uint32_t width, height;             /* of this strip */
+    uint32_t pitch_px;                  /* row pitch of all four planes, in pixels (>= width) */
+    uint32_t y_offset;                  /* global y of row 0 (0 for a whole frame) */
+} mil_gbuffer;
+
+/* ---- build-defined extensions (no counterpart in the reference).
+ * With n_point = 0, shadow = NULL and ambient = 0 the result is bit-identical to
+ * mil_light_directional. ---- */
+
+/* E1 point light, same 32-byte stride as DirectionalLight. */
+typedef struct mil_point_light {
+    float position[3];
+    float radius;
+    float color[3];
+    float intensity;
+} mil_point_light;
+
+/* E3: 3x3 PCF shadow on directional light 0.  `map` is DEVICE memory, size x size
+ * floats, depth 0..1 as seen through light_view_proj (column-major, no w divide). */
+typedef struct mil_shadow {
+    float light_view_proj[16];
+    const float *map;
+    uint32_t size;
+    float bias;
+} mil_shadow;
+
+typedef enum mil_out_format {
+    MIL_OUT_HDR_RGBA32F = 0,  /* hdr attachment, R32G32B32A32_SFLOAT (render/pbr/mod.rs:32), alpha 1 */
+    MIL_OUT_LDR_R11G11B10F = 1, /* tonemapped, B10G11R11_UFLOAT_PACK32 (render/pbr/mod.rs:161-173), RNE */
+    MIL_OUT_SRGB8_BGRA = 2,   /* tonemapped, sRGB OETF, B8G8R8A8 (swapchain format render/renderer.rs:78-83) */
+    MIL_OUT_SRGB8_BGRA_VIA_LDR = 3 /* as the reference chain: tonemap -> R11G11B10F -> sRGB8 (no FXAA) */
+} mil_out_format;
+
+enum {
+    MIL_FLAG_STRICT = 1u << 0,      /* GLSL operator order, IEEE div/sqrt, no FMA contraction: bit-exact vs the CPU oracle */
+    MIL_FLAG_NO_CULL = 1u << 1,     /* point lights by brute force (every light, every pixel) */
+    MIL_FLAG_SHADOW_DIRECT = 1u << 2 /* PCF taps straight from global memory (no LDS staging) */
+};
+
+typedef struct mil_extras {
+    const mil_point_light *point_lights; /* HOST */
+    uint32_t n_point;
+    float ambient[3];                    /* E4: result += ambient * albedo * occlusion */
+    const mil_shadow *shadow;            /* HOST struct, device map; NULL = off */
+} mil_extras;
+
+typedef struct mil_ctx mil_ctx;
+
+/* Context: owns a ring of staged uniform/light buffers sized at creation. */
+int mil_create(mil_ctx **out, int device, uint32_t max_point_lights);
+void mil_destroy(mil_ctx *ctx);
+
+/* Replaces the lighting draw, render/mod.rs:201-216 + shaders/fs_deferred_lighting.glsl:40-67:
+ * hdr = vec4(sum_i light(N, dir_i, V, color_i, alpha, albedo, metallic) * intensity_i * occlusion, 1).
+ * hdr: DEVICE, height x hdr_pitch_px x 4 floats.  push->light_count <= MIL_MAX_DIR_LIGHTS. */
+int mil_light_directional(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                          const mil_directional_light *lights, const mil_push_constants *push,
+                          float *hdr, uint32_t hdr_pitch_px, uint32_t flags, void *stream);
+
+/* Replaces the tonemap draw, render/mod.rs:297-309 + shaders/fs_tonemap.glsl:14-27:
+ * out = encode(clamp(ACESFilm(hdr.rgb), 0, 1)).  out: DEVICE, one u32 per pixel. */
+int mil_tonemap(mil_ctx *ctx, const float *hdr, uint32_t hdr_pitch_px, uint32_t width, uint32_t height,
+                uint32_t *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream);
+
+/* Lighting with the extensions, optionally fused with the tonemap (valid only when
+ * nothing else writes hdr in between, unlike the reference's sky/transparency
+ * subpasses, render/pbr/mod.rs:420-434).  `out` is float4 per pixel for
+ * MIL_OUT_HDR_RGBA32F, else one u32 per pixel; out_pitch_px in pixels.
+ * Point lights are culled per 16x16 tile into LDS lists unless MIL_FLAG_NO_CULL. */
+int mil_light_ex(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                 const mil_directional_light *lights, const mil_push_constants *push,
+                 const mil_extras *extras, void *out, uint32_t out_pitch_px, mil_out_format fmt,
+                 uint32_t flags, void *stream);
+
+/* Diagnostics for the roofline accounting: number of (pixel, point light) pairs
+ * with d^2 < r^2 and occlusion > 0, by brute force (independent of the culling).
+ * count: DEVICE uint64, overwritten. */
+int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                    const mil_push_constants *push, const mil_point_light *point_lights, uint32_t n_point,
+                    unsigned long long *count, void *stream);
+
+/* After a culled mil_light_ex: per-tile light-list lengths of that call are written to
+ * `counts` (DEVICE, tiles_x * tiles_y uint32) when set before the call; NULL disables. */
+int mil_set_tile_count_buffer(mil_ctx *ctx, uint32_t *counts);
+
+int mil_sync(mil_ctx *ctx, void *stream);
+int mil_last_hip_error(const mil_ctx *ctx);
+const char *mil_strerror(int status);
+int mil_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIL_H */

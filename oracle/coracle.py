@@ -1,0 +1,84 @@
+"""ctypes front-end of oracle/libmil_oracle.so (the FP32 C restatement).
+
+TEST INFRASTRUCTURE ONLY — see the header of oracle/mil_oracle.c.  Loaded by
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by
+renderer_amd/.
+"""
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'libmil_oracle.so')
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'mil_oracle.c')
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libmil_oracle.so'], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.milo_pack_r11g11b10f.restype = ctypes.c_uint32
+        _lib.milo_pack_r11g11b10f.argtypes = [ctypes.c_float] * 3
+        _lib.milo_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ct))
+
+
+def max_threads():
+    return int(lib().milo_max_threads())
+
+
+def shade(normal, albedo_occ, rough_metal, depth, frame_ubo, dir_lights, width=None, full_height=None,
+          y_offset=0, point_lights=None, ambient=None, shadow=None, nthreads=0, return_pairs=False):
+    """Same contract as oracle.mil_oracle.shade; returns (h, w, 4) float32."""
+    h, w = depth.shape
+    c = np.ascontiguousarray
+    normal, albedo_occ, rough_metal = (c(normal, np.uint32), c(albedo_occ, np.uint32), c(rough_metal, np.uint32))
+    depth = c(depth, np.float32)
+    ubo = c(frame_ubo, np.float32).reshape(68)
+    dl = c(dir_lights, np.float32).reshape(-1, 8) if dir_lights is not None else np.zeros((0, 8), np.float32)
+    pl = c(point_lights, np.float32).reshape(-1, 8) if point_lights is not None else np.zeros((0, 8), np.float32)
+    amb = c(ambient, np.float32) if ambient is not None else None
+    lvp = smap = None
+    ssize, sbias = 0, 0.0
+    if shadow is not None:
+        lvp = c(shadow['light_view_proj'], np.float32)
+        smap = c(np.asarray(shadow['map']), np.float32)
+        ssize, sbias = smap.shape[0], float(shadow['bias'])
+    hdr = np.empty((h, w, 4), np.float32)
+    pairs = ctypes.c_longlong(0)
+    f, u = ctypes.c_float, ctypes.c_uint32
+    lib().milo_shade(_p(normal, u), _p(albedo_occ, u), _p(rough_metal, u), _p(depth, f),
+                     ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(y_offset),
+                     ctypes.c_int(h if full_height is None else full_height),
+                     _p(ubo, f), _p(dl, f), ctypes.c_int(dl.shape[0]), _p(pl, f), ctypes.c_int(pl.shape[0]),
+                     _p(amb, f), _p(lvp, f), _p(smap, f), ctypes.c_int(ssize), ctypes.c_float(sbias),
+                     _p(hdr, f), ctypes.c_int(nthreads), ctypes.byref(pairs))
+    if width is not None and width != w:
+        raise ValueError('strips are full-width')
+    return (hdr, pairs.value) if return_pairs else hdr
+
+
+def tonemap(hdr, fmt, nthreads=0):
+    hdr = np.ascontiguousarray(hdr, np.float32)
+    h, w = hdr.shape[:2]
+    out = np.empty((h, w), np.uint32)
+    lib().milo_tonemap(_p(hdr, ctypes.c_float), ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(w),
+                       ctypes.c_int(fmt), _p(out, ctypes.c_uint32), ctypes.c_int(nthreads))
+    return out
+
+
+def pack_r11g11b10f(r, g, b):
+    return int(lib().milo_pack_r11g11b10f(float(r), float(g), float(b)))

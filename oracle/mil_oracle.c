@@ -1,0 +1,283 @@
+/*
+ * FP32 C restatement of the reference's deferred-lighting + tonemap shaders, in
+ * GLSL operator order.  TEST INFRASTRUCTURE ONLY: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
+ * product (renderer_amd/, libmil.so) never does.
+ *
+ * PARITY UNPINNED: the reference has no tests, fixtures or golden images for
+ * its render path and cannot be built in this image (no rustc, no GLSL
+ * compiler, no Vulkan ICD).  This file is pinned by the hand-derived known
+ * answers in tests/test_oracle_kat.py and by agreement with the independent
+ * float64 restatement oracle/mil_oracle.py.
+ *
+ * Build (oracle/Makefile): gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp.
+ * With contraction off and SSE arithmetic every operation below is one
+ * correctly-rounded IEEE-754 binary32 operation, which is what makes the
+ * "strict" HIP kernels comparable bit for bit.
+ *
+ * Evaluation rules chosen where GLSL leaves them to the implementation:
+ *   a op b op c            left to right, no FMA contraction
+ *   dot(a,b)               (a.x*b.x + a.y*b.y) + a.z*b.z
+ *   mat4 * vec4            ((c0*v.x + c1*v.y) + c2*v.z) + c3*v.w   (column-major)
+ *   normalize(v)           v * (1.0 / sqrt(dot(v,v)))
+ *   mix(x,y,a)             x*(1-a) + y*a           (GLSL spec definition)
+ *   clamp(x,lo,hi)         min(max(x,lo),hi)
+ *   pow(x,5)               x2=x*x; x4=x2*x2; x4*x
+ *   UNORM decode           (float)c / (2^b - 1)
+ *
+ * All citations are relative to /root/reference/.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI_LIT 3.14159f /* renderer/shaders/inc_brdf.glsl:6,46 */
+
+typedef struct { float x, y, z; } v3;
+
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 normalize3(v3 v)
+{
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    v3 r = { v.x * inv, v.y * inv, v.z * inv };
+    return r;
+}
+/* column-major m[c*4+r] */
+static inline float mrow(const float *m, int r, float x, float y, float z, float w)
+{
+    return ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+
+/* inc_brdf.glsl:2-8 */
+static inline float D_GGX(float roughness, float NdotH)
+{
+    float oneMinusNoHSquared = 1.0f - NdotH * NdotH;
+    float a = NdotH * roughness;
+    float k = roughness / (oneMinusNoHSquared + a * a);
+    float d = (k * k) * (1.0f / PI_LIT);
+    return d;
+}
+
+/* inc_brdf.glsl:14-19 */
+static inline float V_SmithGGXCorrelated(float roughness, float NdotV, float NdotL)
+{
+    float a2 = roughness * roughness;
+    float GGXV = NdotL * sqrtf((NdotV - a2 * NdotV) * NdotV + a2);
+    float GGXL = NdotV * sqrtf((NdotL - a2 * NdotL) * NdotL + a2);
+    return 0.5f / (GGXV + GGXL);
+}
+
+/* inc_brdf.glsl:49-63 light(), with specular() :34-43, fresnel() :25-32, diffuse() :45-47 inlined */
+static inline v3 brdf_light(v3 N, v3 L, v3 V, v3 lightColor, float roughness, v3 albedo, float metallic)
+{
+    v3 Hs = { L.x + V.x, L.y + V.y, L.z + V.z };
+    v3 H = normalize3(Hs);
+    float NdotV = clampf(dot3(N, V), 0.0001f, 1.0f);
+    float NdotL = clampf(dot3(N, L), 0.0f, 1.0f);
+    float NdotH = clampf(dot3(N, H), 0.0f, 1.0f);
+    float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
+
+    float om = 1.0f - metallic;
+    v3 F0 = { 0.04f * om + albedo.x * metallic, 0.04f * om + albedo.y * metallic, 0.04f * om + albedo.z * metallic };
+    float D = D_GGX(roughness, NdotH);
+    float Vis = V_SmithGGXCorrelated(roughness, NdotV, NdotL);
+    const float c = 16.5f; /* 50.0 * 0.33, inc_brdf.glsl:30 */
+    float f90 = clampf((F0.x * c + F0.y * c) + F0.z * c, 0.0f, 1.0f);
+    float x = 1.0f - LdotH, x2 = x * x, x4 = x2 * x2, pw = x4 * x; /* pow(1-VdotH, 5), :26 */
+    v3 F = { F0.x + (f90 - F0.x) * pw, F0.y + (f90 - F0.y) * pw, F0.z + (f90 - F0.z) * pw };
+    float DV = D * Vis;
+    v3 spec = { DV * F.x, DV * F.y, DV * F.z };
+    v3 diff = { albedo.x / PI_LIT, albedo.y / PI_LIT, albedo.z / PI_LIT };
+    /* color = diffuse*(1-metallic) + mix(specular, specular*albedo, metallic)   :60 */
+    v3 color = { diff.x * om + (spec.x * om + (spec.x * albedo.x) * metallic),
+                 diff.y * om + (spec.y * om + (spec.y * albedo.y) * metallic),
+                 diff.z * om + (spec.z * om + (spec.z * albedo.z) * metallic) };
+    v3 r = { (color.x * lightColor.x) * NdotL, (color.y * lightColor.y) * NdotL, (color.z * lightColor.z) * NdotL };
+    return r;
+}
+
+/* EXTENSION E3: 3x3 PCF for directional light 0 */
+static inline float pcf_shadow(v3 P, const float *lvp, const float *map, int S, float bias)
+{
+    float qx = mrow(lvp, 0, P.x, P.y, P.z, 1.0f);
+    float qy = mrow(lvp, 1, P.x, P.y, P.z, 1.0f);
+    float zr = mrow(lvp, 2, P.x, P.y, P.z, 1.0f);
+    float u = qx * 0.5f + 0.5f, v = qy * 0.5f + 0.5f;
+    if (!(u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) || zr > 1.0f) return 1.0f;
+    int tx = (int)floorf(u * (float)S), ty = (int)floorf(v * (float)S);
+    float zc = zr - bias;
+    int cnt = 0;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            int xx = tx + dx, yy = ty + dy;
+            xx = xx < 0 ? 0 : (xx > S - 1 ? S - 1 : xx);
+            yy = yy < 0 ? 0 : (yy > S - 1 ? S - 1 : yy);
+            cnt += (zc <= map[(size_t)yy * S + xx]) ? 1 : 0;
+        }
+    return (float)cnt / 9.0f;
+}
+
+/*
+ * fs_deferred_lighting.glsl:40-67 main(), one call per strip.
+ * frame_ubo: 68 floats (FrameMatrixData, render/ubo.rs:28-41)
+ * dir_lights: n_dir x 8 floats {direction.xyz,intensity,color.xyz,pad} (ubo.rs:54-63)
+ * point_lights: n_point x 8 floats {position.xyz,radius,color.xyz,intensity}   EXTENSION E1
+ * ambient: 3 floats or NULL (EXTENSION E4); shadow_lvp: 16 floats or NULL (EXTENSION E3)
+ * hdr: height x width x 4 floats, densely packed.
+ * pairs_out (optional): number of (pixel, point light) pairs that were in radius.
+ */
+void milo_shade(const uint32_t *normal, const uint32_t *albedo_occ, const uint32_t *rough_metal, const float *depth,
+                int width, int height, int pitch_px, int y_offset, int full_height,
+                const float *frame_ubo, const float *dir_lights, int n_dir,
+                const float *point_lights, int n_point, const float *ambient,
+                const float *shadow_lvp, const float *shadow_map, int shadow_size, float shadow_bias,
+                float *hdr, int nthreads, long long *pairs_out)
+{
+    const float *invProj = frame_ubo + 32, *invView = frame_ubo + 48;
+    const v3 cam = { frame_ubo[64], frame_ubo[65], frame_ubo[66] };
+    const float resx = (float)width, resy = (float)full_height; /* push_constants.resolution, render/mod.rs:211-214 */
+    long long pairs = 0;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : pairs)
+    for (int y = 0; y < height; y++) {
+        for (int x = 0; x < width; x++) {
+            size_t i = (size_t)y * pitch_px + x;
+            uint32_t u1 = normal[i], u2 = albedo_occ[i], u3 = rough_metal[i];
+            /* subpassLoad + UNORM decode (:42-45) */
+            v3 b1 = { (float)(u1 & 0x3FF) / 1023.0f, (float)((u1 >> 10) & 0x3FF) / 1023.0f, (float)((u1 >> 20) & 0x3FF) / 1023.0f };
+            v3 albedo = { (float)(u2 & 0xFF) / 255.0f, (float)((u2 >> 8) & 0xFF) / 255.0f, (float)((u2 >> 16) & 0xFF) / 255.0f };
+            float occlusion = (float)(u2 >> 24) / 255.0f;
+            float roughness = clampf((float)(u3 & 0xFF) / 255.0f, 0.0001f, 1.0f); /* :51 */
+            float metallic = (float)((u3 >> 8) & 0xFF) / 255.0f;
+            v3 nrm = { b1.x * 2.0f - 1.0f, b1.y * 2.0f - 1.0f, b1.z * 2.0f - 1.0f }; /* :48 */
+            /* PositionFromDepth :30-38 */
+            float cx = ((float)x + 0.5f) / resx, cy = ((float)(y + y_offset) + 0.5f) / resy;
+            float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f, pz = depth[i];
+            float vx = mrow(invProj, 0, px, py, pz, 1.0f), vy = mrow(invProj, 1, px, py, pz, 1.0f);
+            float vz = mrow(invProj, 2, px, py, pz, 1.0f), vw = mrow(invProj, 3, px, py, pz, 1.0f);
+            vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
+            v3 P = { mrow(invView, 0, vx, vy, vz, vw), mrow(invView, 1, vx, vy, vz, vw), mrow(invView, 2, vx, vy, vz, vw) };
+            roughness = roughness * roughness; /* :56 */
+            v3 N = normalize3(nrm);
+            v3 toCam = { cam.x - P.x, cam.y - P.y, cam.z - P.z };
+            v3 V = normalize3(toCam);
+
+            float rx = 0.0f, ry = 0.0f, rz = 0.0f;
+            for (int l = 0; l < n_dir; l++) { /* :62-64 */
+                const float *lt = dir_lights + 8 * l;
+                v3 L = { lt[0], lt[1], lt[2] }, col = { lt[4], lt[5], lt[6] };
+                v3 c = brdf_light(N, L, V, col, roughness, albedo, metallic);
+                float ax = (c.x * lt[3]) * occlusion, ay = (c.y * lt[3]) * occlusion, az = (c.z * lt[3]) * occlusion;
+                if (l == 0 && shadow_lvp) {
+                    float s = pcf_shadow(P, shadow_lvp, shadow_map, shadow_size, shadow_bias);
+                    ax = ax * s; ay = ay * s; az = az * s;
+                }
+                rx += ax; ry += ay; rz += az;
+            }
+            for (int l = 0; l < n_point; l++) { /* EXTENSION E1 */
+                const float *lt = point_lights + 8 * l;
+                v3 Lv = { lt[0] - P.x, lt[1] - P.y, lt[2] - P.z };
+                float d2 = dot3(Lv, Lv), r2 = lt[3] * lt[3];
+                if (d2 < r2 && occlusion > 0.0f) {
+                    pairs++;
+                    float inv = 1.0f / sqrtf(fmaxf(d2, 1e-12f));
+                    v3 L = { Lv.x * inv, Lv.y * inv, Lv.z * inv }, col = { lt[4], lt[5], lt[6] };
+                    float q = d2 / r2, w = clampf(1.0f - q * q, 0.0f, 1.0f);
+                    float att = (w * w) / (d2 + 1e-4f);
+                    v3 c = brdf_light(N, L, V, col, roughness, albedo, metallic);
+                    rx += ((c.x * lt[7]) * att) * occlusion;
+                    ry += ((c.y * lt[7]) * att) * occlusion;
+                    rz += ((c.z * lt[7]) * att) * occlusion;
+                }
+            }
+            if (ambient) { /* EXTENSION E4 */
+                rx += (ambient[0] * albedo.x) * occlusion;
+                ry += (ambient[1] * albedo.y) * occlusion;
+                rz += (ambient[2] * albedo.z) * occlusion;
+            }
+            float *o = hdr + ((size_t)y * width + x) * 4;
+            o[0] = rx; o[1] = ry; o[2] = rz; o[3] = 1.0f; /* :66 */
+        }
+    }
+    if (pairs_out) *pairs_out = pairs;
+}
+
+/* fs_tonemap.glsl:14-21 */
+static inline float aces1(float x)
+{
+    float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    return clampf((x * (a * x + b)) / (x * (c * x + d) + e), 0.0f, 1.0f);
+}
+
+/* B10G11R11_UFLOAT_PACK32 channel encode, round-to-nearest-even; x in [0,1] */
+static inline uint32_t ufloat_enc(float x, int mbits)
+{
+    uint32_t bits;
+    memcpy(&bits, &x, 4);
+    int sh = 23 - mbits;
+    if (x >= 6.103515625e-05f) { /* 2^-14: normal in the target format */
+        uint32_t r = bits + ((1u << (sh - 1)) - 1u) + ((bits >> sh) & 1u);
+        return (r >> sh) - ((127u - 15u) << mbits);
+    }
+    return (uint32_t)lrintf(x * (float)(1u << (14 + mbits))); /* denormal: m * 2^-(14+mbits), RNE */
+}
+static inline float ufloat_dec(uint32_t code, int mbits)
+{
+    uint32_t e = code >> mbits, m = code & ((1u << mbits) - 1u);
+    if (e == 0) return (float)m * (1.0f / (float)(1u << (14 + mbits)));
+    return ldexpf(1.0f + (float)m / (float)(1u << mbits), (int)e - 15);
+}
+uint32_t milo_pack_r11g11b10f(float r, float g, float b)
+{
+    return ufloat_enc(r, 6) | (ufloat_enc(g, 6) << 11) | (ufloat_enc(b, 5) << 22);
+}
+void milo_unpack_r11g11b10f(uint32_t u, float *rgb)
+{
+    rgb[0] = ufloat_dec(u & 0x7FF, 6); rgb[1] = ufloat_dec((u >> 11) & 0x7FF, 6); rgb[2] = ufloat_dec(u >> 22, 5);
+}
+
+/* sRGB OETF + 8-bit, B8G8R8A8_SRGB (render/renderer.rs:78-83); double pow so the LUT is exact */
+static inline uint32_t srgb8(double c)
+{
+    c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+    double s = c <= 0.0031308 ? 12.92 * c : 1.055 * pow(c, 1.0 / 2.4) - 0.055;
+    return (uint32_t)floor(s * 255.0 + 0.5);
+}
+
+/* fs_tonemap.glsl:23-27 + attachment encode.  fmt: 1 R11G11B10F, 2 sRGB8 direct, 3 sRGB8 via R11G11B10F */
+void milo_tonemap(const float *hdr, int width, int height, int hdr_pitch_px, int fmt, uint32_t *out, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const float *p = hdr + ((size_t)y * hdr_pitch_px + x) * 4;
+            float r = aces1(p[0]), g = aces1(p[1]), b = aces1(p[2]);
+            uint32_t o;
+            if (fmt == 1) o = milo_pack_r11g11b10f(r, g, b);
+            else if (fmt == 2) o = srgb8(b) | (srgb8(g) << 8) | (srgb8(r) << 16) | 0xFF000000u;
+            else {
+                float q[3];
+                milo_unpack_r11g11b10f(milo_pack_r11g11b10f(r, g, b), q);
+                o = srgb8(q[2]) | (srgb8(q[1]) << 8) | (srgb8(q[0]) << 16) | 0xFF000000u;
+            }
+            out[(size_t)y * width + x] = o;
+        }
+}
+
+int milo_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

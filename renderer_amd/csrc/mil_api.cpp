@@ -1,0 +1,337 @@
+// Host runtime of libmil.so: the C ABI declared in include/mil.h.
+// Owns a small ring of staged light buffers (the counterpart of the reference's
+// per-frame CpuBufferPool ring, render/pools.rs:42-57); everything else belongs to
+// the caller.  No allocation happens after mil_create.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <new>
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/mil.h"
+#include "mil_params.h"
+
+static_assert(sizeof(mil_frame_matrix_data) == 272, "FrameMatrixData is 272 bytes (render/ubo.rs:28-41)");
+static_assert(sizeof(mil_directional_light) == 32, "DirectionalLight std140 stride is 32 (render/ubo.rs:54-63)");
+static_assert(sizeof(mil_point_light) == 32, "point light shares the 32-byte stride");
+static_assert(sizeof(mil_push_constants) == 12, "push constants are 12 bytes (fs_deferred_lighting.glsl:24-27)");
+
+namespace {
+
+constexpr int RING = 4;
+constexpr uint32_t LUT11_N = 0x3C1, LUT10_N = 0x1E1;
+
+struct Slot {
+    uint8_t *host = nullptr; // pinned
+    uint8_t *dev = nullptr;
+    hipEvent_t done = nullptr;
+    bool used = false;
+};
+
+} // namespace
+
+struct mil_ctx {
+    int device = 0;
+    uint32_t max_point = 0;
+    size_t slot_bytes = 0;
+    Slot ring[RING];
+    int next = 0;
+    uint8_t *lut = nullptr; // device: lut11 then lut10
+    uint32_t *tile_counts = nullptr;
+    int last_hip = 0;
+};
+
+namespace {
+
+int hip_fail(mil_ctx *c, hipError_t e)
+{
+    if (c) c->last_hip = (int)e;
+    return MIL_ERR_HIP;
+}
+#define HIP_TRY(c, expr)                                    \
+    do {                                                    \
+        hipError_t e_ = (expr);                             \
+        if (e_ != hipSuccess) return hip_fail((c), e_);     \
+    } while (0)
+
+double ufloat_dec(uint32_t code, int mbits)
+{
+    uint32_t e = code >> mbits, m = code & ((1u << mbits) - 1u);
+    if (e == 0) return ldexp((double)m, -(14 + mbits));
+    return ldexp(1.0 + (double)m / (double)(1u << mbits), (int)e - 15);
+}
+uint8_t srgb8(double c)
+{
+    c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+    double s = c <= 0.0031308 ? 12.92 * c : 1.055 * pow(c, 1.0 / 2.4) - 0.055;
+    return (uint8_t)floor(s * 255.0 + 0.5);
+}
+
+int set_device(mil_ctx *c)
+{
+    int cur = -1;
+    HIP_TRY(c, hipGetDevice(&cur));
+    if (cur != c->device) HIP_TRY(c, hipSetDevice(c->device));
+    return MIL_OK;
+}
+
+int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push)
+{
+    if (!gb || !push) return MIL_ERR_BAD_ARG;
+    if (!gb->normal_l_model || !gb->albedo_occlusion || !gb->roughness_metallic || !gb->depth) return MIL_ERR_BAD_ARG;
+    if (gb->width == 0 || gb->height == 0 || gb->pitch_px < gb->width) return MIL_ERR_BAD_ARG;
+    if (!(push->resolution[0] >= 1.0f) || !(push->resolution[1] >= 1.0f)) return MIL_ERR_BAD_ARG;
+    if ((float)gb->width > push->resolution[0]) return MIL_ERR_BAD_ARG;
+    if ((double)gb->y_offset + (double)gb->height > (double)push->resolution[1]) return MIL_ERR_BAD_ARG;
+    return MIL_OK;
+}
+
+// Stage the light arrays into the next ring slot and fill the light part of ShadeParams.
+// Layout per slot: dir_raw | dir_prep | point_raw | point_prep, each n x 32 bytes.
+int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, const mil_point_light *pl,
+                 uint32_t n_point, hipStream_t s, mil::ShadeParams &p, Slot *&slot_out)
+{
+    Slot &sl = c->ring[c->next];
+    c->next = (c->next + 1) % RING;
+    if (sl.used) HIP_TRY(c, hipEventSynchronize(sl.done)); // slot still in flight from RING calls ago
+    const size_t dir_b = (size_t)MIL_MAX_DIR_LIGHTS * 32, pt_b = (size_t)c->max_point * 32;
+    float *h_dir_raw = (float *)sl.host, *h_dir_prep = (float *)(sl.host + dir_b);
+    float *h_pt_raw = (float *)(sl.host + 2 * dir_b), *h_pt_prep = (float *)(sl.host + 2 * dir_b + pt_b);
+    for (uint32_t i = 0; i < n_dir; i++) {
+        const mil_directional_light &l = dl[i];
+        float *r = h_dir_raw + 8 * i, *q = h_dir_prep + 8 * i;
+        r[0] = l.direction[0]; r[1] = l.direction[1]; r[2] = l.direction[2]; r[3] = l.intensity;
+        r[4] = l.color[0]; r[5] = l.color[1]; r[6] = l.color[2]; r[7] = 0.0f;
+        q[0] = l.direction[0]; q[1] = l.direction[1]; q[2] = l.direction[2]; q[3] = 0.0f;
+        q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity; q[7] = 0.0f;
+    }
+    for (uint32_t i = 0; i < n_point; i++) {
+        const mil_point_light &l = pl[i];
+        float *r = h_pt_raw + 8 * i, *q = h_pt_prep + 8 * i;
+        memcpy(r, &l, 32);
+        const float r2 = l.radius * l.radius;
+        q[0] = l.position[0]; q[1] = l.position[1]; q[2] = l.position[2]; q[3] = r2;
+        q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity;
+        q[7] = 1.0f / r2;
+    }
+    if (n_dir) HIP_TRY(c, hipMemcpyAsync(sl.dev, sl.host, 2 * dir_b, hipMemcpyHostToDevice, s));
+    if (n_point)
+        HIP_TRY(c, hipMemcpyAsync(sl.dev + 2 * dir_b, sl.host + 2 * dir_b, 2 * pt_b, hipMemcpyHostToDevice, s));
+    p.n_dir = n_dir;
+    p.n_point = n_point;
+    p.dir_raw = (const float4 *)sl.dev;
+    p.dir_prep = (const float4 *)(sl.dev + dir_b);
+    p.point_raw = (const float4 *)(sl.dev + 2 * dir_b);
+    p.point_prep = (const float4 *)(sl.dev + 2 * dir_b + pt_b);
+    slot_out = &sl;
+    return MIL_OK;
+}
+
+void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_matrix_data *f, const mil_push_constants *push)
+{
+    memset(&p, 0, sizeof(p));
+    p.normal = gb->normal_l_model; p.albedo = gb->albedo_occlusion; p.rm = gb->roughness_metallic; p.depth = gb->depth;
+    p.width = gb->width; p.height = gb->height; p.pitch = gb->pitch_px; p.y_offset = gb->y_offset;
+    memcpy(p.inv_proj, f->inv_projection, 64);
+    memcpy(p.inv_view, f->inv_view, 64);
+    memcpy(p.cam, f->camera_position, 12);
+    p.res_x = push->resolution[0]; p.res_y = push->resolution[1];
+    p.sx = 2.0f / p.res_x; p.ox = 1.0f / p.res_x - 1.0f;
+    p.sy = 2.0f / p.res_y; p.oy = 1.0f / p.res_y - 1.0f;
+    p.tiles_x = (gb->width + MIL_TILE - 1) / MIL_TILE;
+    p.tiles_y = (gb->height + MIL_TILE - 1) / MIL_TILE;
+}
+
+int finish(mil_ctx *c, Slot *sl, hipStream_t s)
+{
+    HIP_TRY(c, hipGetLastError());
+    if (sl) {
+        HIP_TRY(c, hipEventRecord(sl->done, s));
+        sl->used = true;
+    }
+    return MIL_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mil_version(void) { return MIL_VERSION; }
+
+const char *mil_strerror(int st)
+{
+    switch (st) {
+    case MIL_OK: return "ok";
+    case MIL_ERR_BAD_ARG: return "bad argument";
+    case MIL_ERR_TOO_MANY_LIGHTS: return "more than MIL_MAX_DIR_LIGHTS directional lights";
+    case MIL_ERR_HIP: return "HIP runtime error (see mil_last_hip_error)";
+    case MIL_ERR_NO_DEVICE: return "no such HIP device";
+    case MIL_ERR_CAPACITY: return "more point lights than the context capacity";
+    default: return "unknown status";
+    }
+}
+
+int mil_last_hip_error(const mil_ctx *c) { return c ? c->last_hip : 0; }
+
+int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
+{
+    if (!out) return MIL_ERR_BAD_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MIL_ERR_NO_DEVICE;
+    mil_ctx *c = new (std::nothrow) mil_ctx();
+    if (!c) return MIL_ERR_HIP;
+    c->device = device;
+    c->max_point = max_point_lights;
+    c->slot_bytes = 2 * ((size_t)MIL_MAX_DIR_LIGHTS * 32 + (size_t)max_point_lights * 32);
+    int rc = set_device(c);
+    for (int i = 0; rc == MIL_OK && i < RING; i++) {
+        Slot &s = c->ring[i];
+        if (hipHostMalloc((void **)&s.host, c->slot_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&s.dev, c->slot_bytes) != hipSuccess ||
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+            rc = MIL_ERR_HIP;
+    }
+    if (rc == MIL_OK) {
+        uint8_t h[LUT11_N + LUT10_N];
+        for (uint32_t i = 0; i < LUT11_N; i++) h[i] = srgb8(ufloat_dec(i, 6));
+        for (uint32_t i = 0; i < LUT10_N; i++) h[LUT11_N + i] = srgb8(ufloat_dec(i, 5));
+        if (hipMalloc((void **)&c->lut, sizeof(h)) != hipSuccess ||
+            hipMemcpy(c->lut, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess)
+            rc = MIL_ERR_HIP;
+    }
+    if (rc != MIL_OK) {
+        mil_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return MIL_OK;
+}
+
+void mil_destroy(mil_ctx *c)
+{
+    if (!c) return;
+    set_device(c);
+    for (Slot &s : c->ring) {
+        if (s.used) hipEventSynchronize(s.done);
+        if (s.done) hipEventDestroy(s.done);
+        if (s.host) hipHostFree(s.host);
+        if (s.dev) hipFree(s.dev);
+    }
+    if (c->lut) hipFree(c->lut);
+    delete c;
+}
+
+int mil_set_tile_count_buffer(mil_ctx *c, uint32_t *counts)
+{
+    if (!c) return MIL_ERR_BAD_ARG;
+    c->tile_counts = counts;
+    return MIL_OK;
+}
+
+int mil_sync(mil_ctx *c, void *stream)
+{
+    if (!c) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize((hipStream_t)stream));
+    return MIL_OK;
+}
+
+int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                 const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                 void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
+{
+    if (!c || !frame || !out) return MIL_ERR_BAD_ARG;
+    int rc = check_gbuffer(gb, push);
+    if (rc) return rc;
+    if (out_pitch_px < gb->width || (unsigned)fmt > MIL_OUT_SRGB8_BGRA_VIA_LDR) return MIL_ERR_BAD_ARG;
+    if (push->light_count > MIL_MAX_DIR_LIGHTS) return MIL_ERR_TOO_MANY_LIGHTS;
+    if (push->light_count && !lights) return MIL_ERR_BAD_ARG;
+    const uint32_t n_point = ex ? ex->n_point : 0;
+    if (n_point > c->max_point) return MIL_ERR_CAPACITY;
+    if (n_point && !ex->point_lights) return MIL_ERR_BAD_ARG;
+    const mil_shadow *sh = ex ? ex->shadow : nullptr;
+    if (sh && (!sh->map || sh->size == 0)) return MIL_ERR_BAD_ARG;
+    if ((rc = set_device(c))) return rc;
+
+    hipStream_t s = (hipStream_t)stream;
+    mil::ShadeParams p;
+    fill_common(p, gb, frame, push);
+    Slot *slot = nullptr;
+    if ((rc = stage_lights(c, lights, push->light_count, ex ? ex->point_lights : nullptr, n_point, s, p, slot))) return rc;
+    if (ex && (ex->ambient[0] != 0.0f || ex->ambient[1] != 0.0f || ex->ambient[2] != 0.0f)) {
+        p.has_ambient = 1;
+        memcpy(p.ambient, ex->ambient, 12);
+    }
+    if (sh) {
+        p.has_shadow = 1;
+        p.shadow_size = sh->size;
+        p.shadow_bias = sh->bias;
+        p.shadow_map = sh->map;
+        p.shadow_lds = (flags & MIL_FLAG_SHADOW_DIRECT) ? 0u : 1u;
+        memcpy(p.lvp, sh->light_view_proj, 64);
+    }
+    p.out = out;
+    p.out_pitch = out_pitch_px;
+    p.lut11 = c->lut;
+    p.lut10 = c->lut + LUT11_N;
+
+    const bool strict = (flags & MIL_FLAG_STRICT) != 0;
+    const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
+    if (tiled) {
+        p.tile_counts = c->tile_counts;
+        if (strict) mil::strict::launch_tiled((int)fmt, p, s);
+        else mil::fast::launch_tiled((int)fmt, p, s);
+    } else {
+        if (strict) mil::strict::launch_stream((int)fmt, p, s);
+        else mil::fast::launch_stream((int)fmt, p, s);
+    }
+    return finish(c, slot, s);
+}
+
+int mil_light_directional(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                          const mil_directional_light *lights, const mil_push_constants *push, float *hdr,
+                          uint32_t hdr_pitch_px, uint32_t flags, void *stream)
+{
+    return mil_light_ex(c, gb, frame, lights, push, nullptr, hdr, hdr_pitch_px, MIL_OUT_HDR_RGBA32F,
+                        flags & MIL_FLAG_STRICT, stream);
+}
+
+int mil_tonemap(mil_ctx *c, const float *hdr, uint32_t hdr_pitch_px, uint32_t width, uint32_t height, uint32_t *out,
+                uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
+{
+    if (!c || !hdr || !out || width == 0 || height == 0) return MIL_ERR_BAD_ARG;
+    if (hdr_pitch_px < width || out_pitch_px < width) return MIL_ERR_BAD_ARG;
+    if (fmt != MIL_OUT_LDR_R11G11B10F && fmt != MIL_OUT_SRGB8_BGRA && fmt != MIL_OUT_SRGB8_BGRA_VIA_LDR) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    mil::TonemapParams p;
+    p.hdr = (const float4 *)hdr; p.out = out; p.width = width; p.height = height;
+    p.hdr_pitch = hdr_pitch_px; p.out_pitch = out_pitch_px;
+    p.lut11 = c->lut; p.lut10 = c->lut + LUT11_N;
+    if (flags & MIL_FLAG_STRICT) mil::strict::launch_tonemap((int)fmt, p, (hipStream_t)stream);
+    else mil::fast::launch_tonemap((int)fmt, p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream);
+}
+
+int mil_count_pairs(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_push_constants *push,
+                    const mil_point_light *pl, uint32_t n_point, unsigned long long *count, void *stream)
+{
+    if (!c || !frame || !count) return MIL_ERR_BAD_ARG;
+    int rc = check_gbuffer(gb, push);
+    if (rc) return rc;
+    if (n_point > c->max_point) return MIL_ERR_CAPACITY;
+    if (n_point && !pl) return MIL_ERR_BAD_ARG;
+    if ((rc = set_device(c))) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    mil::ShadeParams p;
+    fill_common(p, gb, frame, push);
+    Slot *slot = nullptr;
+    if ((rc = stage_lights(c, nullptr, 0, pl, n_point, s, p, slot))) return rc;
+    HIP_TRY(c, hipMemsetAsync(count, 0, sizeof(unsigned long long), s));
+    mil::fast::launch_count_pairs(p, count, s);
+    return finish(c, slot, s);
+}
+
+} // extern "C"

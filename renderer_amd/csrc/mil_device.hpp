@@ -1,0 +1,681 @@
+// Device code of libmil: deferred lighting (directional, tiled point lights, PCF
+// shadow, ambient) and ACES tonemap / pack for gfx950.  Included twice:
+//   mil_fast.hip    MIL_STRICT=0  hoisted per-pixel invariants, v_rcp/v_rsq/v_sqrt, FMA
+//   mil_strict.hip  MIL_STRICT=1  (-ffp-contract=off) literal GLSL operator order with
+//                                  IEEE divide / sqrt: bit-exact against oracle/mil_oracle.c
+// What the arithmetic follows (paths relative to /root/reference/):
+//   renderer/shaders/fs_deferred_lighting.glsl:30-67, inc_brdf.glsl:2-63, fs_tonemap.glsl:14-27.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mil_params.h"
+
+#ifndef MIL_STRICT
+#error "define MIL_STRICT to 0 or 1"
+#endif
+#if MIL_STRICT
+#define MIL_NS strict
+#else
+#define MIL_NS fast
+#endif
+
+#define DEV static __device__ __forceinline__
+
+namespace mil {
+namespace MIL_NS {
+
+constexpr float PI_LIT = 3.14159f;   // inc_brdf.glsl:6,46 (literal, not pi)
+constexpr int TILE = 16;
+constexpr int CHUNK = 1024;          // point lights culled per LDS pass (4 waves x 256)
+constexpr int SUB = CHUNK / 4;
+constexpr int SH_CAP = 4096;         // floats of shadow map staged in LDS per tile (16 KiB)
+
+enum { FMT_HDR = 0, FMT_LDR = 1, FMT_SRGB8 = 2, FMT_SRGB8_VIA_LDR = 3 };
+
+struct f3 { float x, y, z; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+DEV float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+
+// uniform (wave-invariant) fetch of a staged light record through the scalar cache
+typedef const __attribute__((address_space(4))) v4f *cptr4;
+DEV v4f ldu(const float4 *p, uint32_t i) { return ((cptr4)(uintptr_t)p)[i]; }
+
+// ---------------------------------------------------------------------------------
+// per-pixel state
+// ---------------------------------------------------------------------------------
+struct Px {
+    f3 N, V, P;
+    float occ;
+#if MIL_STRICT
+    f3 albedo;
+    float alpha, metallic;
+#else
+    float alpha, a2, am1, NdotV, sV;   // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
+    f3 F0, dF;                         // dF = f90 - F0
+    f3 dif, tint;                      // albedo/PI*(1-m)*occ ; ((1-m) + albedo*m)*occ
+    f3 albocc;                         // albedo*occ (ambient)
+#endif
+};
+
+#if MIL_STRICT
+// ---- literal transcription, one IEEE operation per GLSL operator ----
+DEV float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+DEV f3 normalize3(f3 v)
+{
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    return f3{ v.x * inv, v.y * inv, v.z * inv };
+}
+DEV float mrow(const float *m, int r, float x, float y, float z, float w)
+{
+    return ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
+}
+
+DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth)
+{
+    f3 b1 = { (float)(u1 & 0x3FF) / 1023.0f, (float)((u1 >> 10) & 0x3FF) / 1023.0f, (float)((u1 >> 20) & 0x3FF) / 1023.0f };
+    q.albedo = f3{ (float)(u2 & 0xFF) / 255.0f, (float)((u2 >> 8) & 0xFF) / 255.0f, (float)((u2 >> 16) & 0xFF) / 255.0f };
+    q.occ = (float)(u2 >> 24) / 255.0f;
+    float roughness = clampf((float)(u3 & 0xFF) / 255.0f, 0.0001f, 1.0f);     // fs_deferred_lighting.glsl:51
+    q.metallic = (float)((u3 >> 8) & 0xFF) / 255.0f;
+    f3 nrm = { b1.x * 2.0f - 1.0f, b1.y * 2.0f - 1.0f, b1.z * 2.0f - 1.0f };  // :48
+    // PositionFromDepth :30-38
+    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
+    float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
+    float vx = mrow(p.inv_proj, 0, px, py, depth, 1.0f), vy = mrow(p.inv_proj, 1, px, py, depth, 1.0f);
+    float vz = mrow(p.inv_proj, 2, px, py, depth, 1.0f), vw = mrow(p.inv_proj, 3, px, py, depth, 1.0f);
+    vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
+    q.P = f3{ mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
+    q.alpha = roughness * roughness;                                         // :56
+    q.N = normalize3(nrm);                                                   // :58
+    q.V = normalize3(f3{ p.cam[0] - q.P.x, p.cam[1] - q.P.y, p.cam[2] - q.P.z }); // :59
+}
+
+// inc_brdf.glsl:49-63 with specular() :34-43, D_GGX :2-8, V_SmithGGXCorrelated :14-19, fresnel :25-32, diffuse :45-47
+DEV f3 brdf_light(const Px &q, f3 L, f3 lightColor)
+{
+    f3 H = normalize3(f3{ L.x + q.V.x, L.y + q.V.y, L.z + q.V.z });
+    float NdotV = clampf(dot3(q.N, q.V), 0.0001f, 1.0f);
+    float NdotL = clampf(dot3(q.N, L), 0.0f, 1.0f);
+    float NdotH = clampf(dot3(q.N, H), 0.0f, 1.0f);
+    float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
+    float om = 1.0f - q.metallic;
+    f3 F0 = { 0.04f * om + q.albedo.x * q.metallic, 0.04f * om + q.albedo.y * q.metallic, 0.04f * om + q.albedo.z * q.metallic };
+    float oneMinusNoHSquared = 1.0f - NdotH * NdotH;
+    float a = NdotH * q.alpha;
+    float k = q.alpha / (oneMinusNoHSquared + a * a);
+    float D = (k * k) * (1.0f / PI_LIT);
+    float a2 = q.alpha * q.alpha;
+    float GGXV = NdotL * sqrtf((NdotV - a2 * NdotV) * NdotV + a2);
+    float GGXL = NdotV * sqrtf((NdotL - a2 * NdotL) * NdotL + a2);
+    float Vis = 0.5f / (GGXV + GGXL);
+    const float c = 16.5f;
+    float f90 = clampf((F0.x * c + F0.y * c) + F0.z * c, 0.0f, 1.0f);
+    float w = 1.0f - LdotH, w2 = w * w, w4 = w2 * w2, pw = w4 * w;
+    f3 F = { F0.x + (f90 - F0.x) * pw, F0.y + (f90 - F0.y) * pw, F0.z + (f90 - F0.z) * pw };
+    float DV = D * Vis;
+    f3 spec = { DV * F.x, DV * F.y, DV * F.z };
+    f3 diff = { q.albedo.x / PI_LIT, q.albedo.y / PI_LIT, q.albedo.z / PI_LIT };
+    f3 color = { diff.x * om + (spec.x * om + (spec.x * q.albedo.x) * q.metallic),
+                 diff.y * om + (spec.y * om + (spec.y * q.albedo.y) * q.metallic),
+                 diff.z * om + (spec.z * om + (spec.z * q.albedo.z) * q.metallic) };
+    return f3{ (color.x * lightColor.x) * NdotL, (color.y * lightColor.y) * NdotL, (color.z * lightColor.z) * NdotL };
+}
+
+DEV void add_directional(const Px &q, const ShadeParams &p, uint32_t l, float shadow, bool use_shadow, f3 &res)
+{
+    v4f a = ldu(p.dir_raw, 2 * l), b = ldu(p.dir_raw, 2 * l + 1);
+    f3 c = brdf_light(q, f3{ a.x, a.y, a.z }, f3{ b.x, b.y, b.z });
+    float ax = (c.x * a.w) * q.occ, ay = (c.y * a.w) * q.occ, az = (c.z * a.w) * q.occ;  // fs_deferred_lighting.glsl:63
+    if (use_shadow) { ax = ax * shadow; ay = ay * shadow; az = az * shadow; }
+    res.x += ax; res.y += ay; res.z += az;
+}
+
+// EXTENSION E1.  d2 and the in-range predicate are shared with the culling (see box_d2).
+DEV float point_d2(const Px &q, v4f a, f3 &Lv)
+{
+    Lv = f3{ a.x - q.P.x, a.y - q.P.y, a.z - q.P.z };
+    return dot3(Lv, Lv);
+}
+DEV float point_r2(v4f a) { return a.w * a.w; }
+DEV void add_point(const Px &q, const ShadeParams &p, uint32_t l, f3 &res)
+{
+    v4f a = ldu(p.point_raw, 2 * l), b = ldu(p.point_raw, 2 * l + 1);
+    f3 Lv;
+    float d2 = point_d2(q, a, Lv), r2 = point_r2(a);
+    if (d2 < r2 && q.occ > 0.0f) {
+        float inv = 1.0f / sqrtf(fmaxf(d2, 1e-12f));
+        f3 L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
+        float qq = d2 / r2, w = clampf(1.0f - qq * qq, 0.0f, 1.0f);
+        float att = (w * w) / (d2 + 1e-4f);
+        f3 c = brdf_light(q, L, f3{ b.x, b.y, b.z });
+        res.x += ((c.x * b.w) * att) * q.occ;
+        res.y += ((c.y * b.w) * att) * q.occ;
+        res.z += ((c.z * b.w) * att) * q.occ;
+    }
+}
+DEV void add_ambient(const Px &q, const ShadeParams &p, f3 &res)
+{
+    res.x += (p.ambient[0] * q.albedo.x) * q.occ;
+    res.y += (p.ambient[1] * q.albedo.y) * q.occ;
+    res.z += (p.ambient[2] * q.albedo.z) * q.occ;
+}
+DEV void shadow_coords(const Px &q, const ShadeParams &p, float &u, float &v, float &zr)
+{
+    float qx = mrow(p.lvp, 0, q.P.x, q.P.y, q.P.z, 1.0f), qy = mrow(p.lvp, 1, q.P.x, q.P.y, q.P.z, 1.0f);
+    zr = mrow(p.lvp, 2, q.P.x, q.P.y, q.P.z, 1.0f);
+    u = qx * 0.5f + 0.5f; v = qy * 0.5f + 0.5f;
+}
+DEV float pcf_result(int cnt) { return (float)cnt / 9.0f; }
+DEV float aces1(float x)
+{
+    return clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
+}
+DEV uint32_t srgb8_direct(float c)
+{
+    float s = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
+    return (uint32_t)floorf(s * 255.0f + 0.5f);
+}
+
+#else
+// ---- fast path: same formulas, light-invariant terms hoisted, hardware rcp/rsq/sqrt ----
+DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
+DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+DEV float dot3(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+DEV float mrow1(const float *m, int r, float x, float y, float z)   // w == 1
+{
+    return __builtin_fmaf(m[0 + r], x, __builtin_fmaf(m[4 + r], y, __builtin_fmaf(m[8 + r], z, m[12 + r])));
+}
+
+DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth)
+{
+    const float k10 = 2.0f / 1023.0f, k8 = 1.0f / 255.0f;
+    f3 nrm = { __builtin_fmaf((float)(u1 & 0x3FF), k10, -1.0f), __builtin_fmaf((float)((u1 >> 10) & 0x3FF), k10, -1.0f),
+               __builtin_fmaf((float)((u1 >> 20) & 0x3FF), k10, -1.0f) };
+    f3 albedo = { (float)(u2 & 0xFF) * k8, (float)((u2 >> 8) & 0xFF) * k8, (float)((u2 >> 16) & 0xFF) * k8 };
+    q.occ = (float)(u2 >> 24) * k8;
+    float roughness = fmaxf((float)(u3 & 0xFF) * k8, 0.0001f);
+    float m = (float)((u3 >> 8) & 0xFF) * k8;
+    float px = __builtin_fmaf((float)x, p.sx, p.ox), py = __builtin_fmaf((float)(y + p.y_offset), p.sy, p.oy);
+    float vx = mrow1(p.inv_proj, 0, px, py, depth), vy = mrow1(p.inv_proj, 1, px, py, depth);
+    float vz = mrow1(p.inv_proj, 2, px, py, depth), vw = mrow1(p.inv_proj, 3, px, py, depth);
+    float iw = rcp_(vw);
+    vx *= iw; vy *= iw; vz *= iw;
+    q.P = f3{ mrow1(p.inv_view, 0, vx, vy, vz), mrow1(p.inv_view, 1, vx, vy, vz), mrow1(p.inv_view, 2, vx, vy, vz) };
+    float rn = rsq_(dot3(nrm, nrm));
+    q.N = f3{ nrm.x * rn, nrm.y * rn, nrm.z * rn };
+    f3 tc = { p.cam[0] - q.P.x, p.cam[1] - q.P.y, p.cam[2] - q.P.z };
+    float rv = rsq_(dot3(tc, tc));
+    q.V = f3{ tc.x * rv, tc.y * rv, tc.z * rv };
+    q.alpha = roughness * roughness;
+    q.a2 = q.alpha * q.alpha;
+    q.am1 = q.a2 - 1.0f;
+    q.NdotV = __builtin_amdgcn_fmed3f(dot3(q.N, q.V), 0.0001f, 1.0f);
+    q.sV = sqrt_(__builtin_fmaf(__builtin_fmaf(-q.a2, q.NdotV, q.NdotV), q.NdotV, q.a2));
+    float om = 1.0f - m;
+    q.F0 = f3{ __builtin_fmaf(albedo.x, m, 0.04f * om), __builtin_fmaf(albedo.y, m, 0.04f * om), __builtin_fmaf(albedo.z, m, 0.04f * om) };
+    float f90 = sat((q.F0.x + q.F0.y + q.F0.z) * 16.5f);
+    q.dF = f3{ f90 - q.F0.x, f90 - q.F0.y, f90 - q.F0.z };
+    float ds = om * q.occ * (1.0f / PI_LIT);
+    q.dif = f3{ albedo.x * ds, albedo.y * ds, albedo.z * ds };
+    q.tint = f3{ __builtin_fmaf(albedo.x, m, om) * q.occ, __builtin_fmaf(albedo.y, m, om) * q.occ, __builtin_fmaf(albedo.z, m, om) * q.occ };
+    q.albocc = f3{ albedo.x * q.occ, albedo.y * q.occ, albedo.z * q.occ };
+}
+
+// light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow]
+DEV void eval_light(const Px &q, f3 L, f3 rad, f3 &res)
+{
+    f3 H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
+    float rh = rsq_(dot3(H, H));
+    float NdotL = sat(dot3(q.N, L));
+    float NdotH = sat(dot3(q.N, H) * rh);
+    float LdotH = sat(dot3(L, H) * rh);
+    float x2 = NdotH * NdotH;
+    float k = q.alpha * rcp_(__builtin_fmaf(x2, q.am1, 1.0f));          // alpha / ((1-x2) + x2*alpha^2)
+    float sL = sqrt_(__builtin_fmaf(__builtin_fmaf(-q.a2, NdotL, NdotL), NdotL, q.a2));
+    float den = __builtin_fmaf(NdotL, q.sV, q.NdotV * sL);               // GGXV + GGXL
+    float DV = (k * k) * ((0.5f / PI_LIT) * rcp_(den));                  // D * Vis
+    float w = 1.0f - LdotH, w2 = w * w, w5 = w2 * w2 * w;
+    float sx = __builtin_fmaf(q.dF.x, w5, q.F0.x) * DV, sy = __builtin_fmaf(q.dF.y, w5, q.F0.y) * DV, sz = __builtin_fmaf(q.dF.z, w5, q.F0.z) * DV;
+    float cx = __builtin_fmaf(sx, q.tint.x, q.dif.x), cy = __builtin_fmaf(sy, q.tint.y, q.dif.y), cz = __builtin_fmaf(sz, q.tint.z, q.dif.z);
+    res.x = __builtin_fmaf(cx, rad.x * NdotL, res.x);
+    res.y = __builtin_fmaf(cy, rad.y * NdotL, res.y);
+    res.z = __builtin_fmaf(cz, rad.z * NdotL, res.z);
+}
+
+DEV void add_directional(const Px &q, const ShadeParams &p, uint32_t l, float shadow, bool use_shadow, f3 &res)
+{
+    v4f a = ldu(p.dir_prep, 2 * l), b = ldu(p.dir_prep, 2 * l + 1);
+    f3 rad = { b.x, b.y, b.z };
+    if (use_shadow) { rad.x *= shadow; rad.y *= shadow; rad.z *= shadow; }
+    eval_light(q, f3{ a.x, a.y, a.z }, rad, res);
+}
+
+DEV float point_d2(const Px &q, v4f a, f3 &Lv)
+{
+    Lv = f3{ a.x - q.P.x, a.y - q.P.y, a.z - q.P.z };
+    return __builtin_fmaf(Lv.z, Lv.z, __builtin_fmaf(Lv.y, Lv.y, Lv.x * Lv.x));
+}
+DEV float point_r2(v4f a) { return a.w; }   // prepared record carries r*r
+DEV void add_point(const Px &q, const ShadeParams &p, uint32_t l, f3 &res)
+{
+    v4f a = ldu(p.point_prep, 2 * l), b = ldu(p.point_prep, 2 * l + 1);
+    f3 Lv;
+    float d2 = point_d2(q, a, Lv);
+    bool on = d2 < a.w && q.occ > 0.0f;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) return;           // wave-uniform early out
+    float inv = rsq_(fmaxf(d2, 1e-12f));
+    f3 L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
+    float qq = d2 * b.w, w = sat(__builtin_fmaf(-qq, qq, 1.0f));
+    float att = on ? (w * w) * rcp_(d2 + 1e-4f) : 0.0f;         // select, not multiply: 0 stays 0 for non-finite BRDF values
+    f3 t = { 0.0f, 0.0f, 0.0f };
+    eval_light(q, L, f3{ b.x * att, b.y * att, b.z * att }, t);
+    if (on) { res.x += t.x; res.y += t.y; res.z += t.z; }
+}
+DEV void add_ambient(const Px &q, const ShadeParams &p, f3 &res)
+{
+    res.x = __builtin_fmaf(p.ambient[0], q.albocc.x, res.x);
+    res.y = __builtin_fmaf(p.ambient[1], q.albocc.y, res.y);
+    res.z = __builtin_fmaf(p.ambient[2], q.albocc.z, res.z);
+}
+DEV void shadow_coords(const Px &q, const ShadeParams &p, float &u, float &v, float &zr)
+{
+    float qx = mrow1(p.lvp, 0, q.P.x, q.P.y, q.P.z), qy = mrow1(p.lvp, 1, q.P.x, q.P.y, q.P.z);
+    zr = mrow1(p.lvp, 2, q.P.x, q.P.y, q.P.z);
+    u = __builtin_fmaf(qx, 0.5f, 0.5f); v = __builtin_fmaf(qy, 0.5f, 0.5f);
+}
+DEV float pcf_result(int cnt) { return (float)cnt * (1.0f / 9.0f); }
+DEV float aces1(float x)
+{
+    float num = x * __builtin_fmaf(2.51f, x, 0.03f), den = __builtin_fmaf(x, __builtin_fmaf(2.43f, x, 0.59f), 0.14f);
+    return clampf(num * rcp_(den), 0.0f, 1.0f);
+}
+DEV uint32_t srgb8_direct(float c)
+{
+    float s = c <= 0.0031308f ? 12.92f * c
+                              : __builtin_fmaf(1.055f, __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(c) * (1.0f / 2.4f)), -0.055f);
+    return (uint32_t)__builtin_fmaf(s, 255.0f, 0.5f);
+}
+#endif // MIL_STRICT
+
+// ---------------------------------------------------------------------------------
+// EXTENSION E3: PCF.  The integer texel / validity logic is identical in both modes.
+// ---------------------------------------------------------------------------------
+struct ShadowTap { int tx, ty; float zc; bool inside; };
+
+DEV ShadowTap shadow_tap(const Px &q, const ShadeParams &p)
+{
+    float u, v, zr;
+    shadow_coords(q, p, u, v, zr);
+    ShadowTap t;
+    t.inside = (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) && !(zr > 1.0f);
+    float S = (float)p.shadow_size;
+    t.tx = t.inside ? (int)floorf(u * S) : 0;
+    t.ty = t.inside ? (int)floorf(v * S) : 0;
+    t.zc = zr - p.shadow_bias;
+    return t;
+}
+DEV float pcf_direct(const ShadowTap &t, const ShadeParams &p)
+{
+    if (!t.inside) return 1.0f;
+    int S = (int)p.shadow_size, cnt = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+        int yy = min(max(t.ty + dy, 0), S - 1);
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            int xx = min(max(t.tx + dx, 0), S - 1);
+            cnt += (t.zc <= p.shadow_map[(size_t)yy * S + xx]) ? 1 : 0;
+        }
+    }
+    return pcf_result(cnt);
+}
+
+// ---------------------------------------------------------------------------------
+// output encode (fs_tonemap.glsl:23-27 + attachment formats)
+// ---------------------------------------------------------------------------------
+DEV uint32_t ufloat_enc(float x, int mbits)
+{
+    uint32_t bits = __float_as_uint(x);
+    int sh = 23 - mbits;
+    if (x >= 6.103515625e-05f) {
+        uint32_t r = bits + ((1u << (sh - 1)) - 1u) + ((bits >> sh) & 1u);
+        return (r >> sh) - ((127u - 15u) << mbits);
+    }
+    return (uint32_t)__builtin_rintf(x * (float)(1u << (14 + mbits)));
+}
+DEV uint32_t pack_r11g11b10f(float r, float g, float b)
+{
+    return ufloat_enc(r, 6) | (ufloat_enc(g, 6) << 11) | (ufloat_enc(b, 5) << 22);
+}
+template <int FMT>
+DEV uint32_t encode_ldr(float r, float g, float b, const uint8_t *lut11, const uint8_t *lut10)
+{
+    r = aces1(r); g = aces1(g); b = aces1(b);
+    if (FMT == FMT_LDR) return pack_r11g11b10f(r, g, b);
+    if (FMT == FMT_SRGB8) return srgb8_direct(b) | (srgb8_direct(g) << 8) | (srgb8_direct(r) << 16) | 0xFF000000u;
+    uint32_t cr = ufloat_enc(r, 6), cg = ufloat_enc(g, 6), cb = ufloat_enc(b, 5);
+    return (uint32_t)lut10[cb] | ((uint32_t)lut11[cg] << 8) | ((uint32_t)lut11[cr] << 16) | 0xFF000000u;
+}
+template <int FMT>
+DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res)
+{
+    size_t o = (size_t)y * p.out_pitch + x;
+    if (FMT == FMT_HDR) {
+        __builtin_nontemporal_store(v4f{ res.x, res.y, res.z, 1.0f }, (v4f *)p.out + o);   // fs_deferred_lighting.glsl:66
+    } else {
+        __builtin_nontemporal_store(encode_ldr<FMT>(res.x, res.y, res.z, p.lut11, p.lut10), (uint32_t *)p.out + o);
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K1: streaming kernel.  Block = 64 x 4 pixels; each wave reads one 256-byte row
+// segment per plane and writes one contiguous 1 KiB (HDR) or 256 B (packed) segment.
+// Handles directional lights, shadow by direct taps, brute-force point lights, ambient.
+// ---------------------------------------------------------------------------------
+template <int FMT>
+__global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
+{
+    uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.width || y >= p.height) return;
+    size_t i = (size_t)y * p.pitch + x;
+    uint32_t u1 = __builtin_nontemporal_load(p.normal + i), u2 = __builtin_nontemporal_load(p.albedo + i);
+    uint32_t u3 = __builtin_nontemporal_load(p.rm + i);
+    float depth = __builtin_nontemporal_load(p.depth + i);
+    Px q;
+    setup_pixel(q, p, x, y, u1, u2, u3, depth);
+    f3 res = { 0.0f, 0.0f, 0.0f };
+    float shadow = 1.0f;
+    if (p.has_shadow && p.n_dir > 0) shadow = pcf_direct(shadow_tap(q, p), p);
+    for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, p, l, shadow, p.has_shadow && l == 0, res);
+    for (uint32_t l = 0; l < p.n_point; l++) add_point(q, p, l, res);
+    if (p.has_ambient) add_ambient(q, p, res);
+    store_pixel<FMT>(p, x, y, res);
+}
+
+// ---------------------------------------------------------------------------------
+// K2: tiled kernel.  One 256-thread workgroup per 16x16 screen tile.
+//  1. every thread reconstructs its pixel; the tile's world-space AABB of lit pixels
+//     is reduced per wave (cross-lane) and across the 4 waves through LDS;
+//  2. shadow: the tile's texel rectangle (+1 apron) is staged into LDS when it fits;
+//  3. point lights, CHUNK at a time: wave w tests its quarter of the chunk 64 lights
+//     per step against the AABB; survivors are appended to the wave's LDS sub-list
+//     with ballot + prefix popcount, so every list stays in ascending light order and
+//     the sum order equals the brute-force loop's (culled == unculled, bit for bit);
+//  4. all threads walk the four sub-lists, fetching each record through the scalar cache.
+// ---------------------------------------------------------------------------------
+DEV float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+DEV float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+DEV int wave_mini(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+DEV int wave_maxi(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// squared distance from a light centre to the tile AABB, formed with the same
+// operation sequence as point_d2 so that  pixel in range  =>  box in range  holds
+// exactly under rounding (each step is monotone in |component|).
+DEV float box_d2(v4f a, f3 lo, f3 hi)
+{
+    float dx = fmaxf(fmaxf(lo.x - a.x, a.x - hi.x), 0.0f);
+    float dy = fmaxf(fmaxf(lo.y - a.y, a.y - hi.y), 0.0f);
+    float dz = fmaxf(fmaxf(lo.z - a.z, a.z - hi.z), 0.0f);
+#if MIL_STRICT
+    return (dx * dx + dy * dy) + dz * dz;
+#else
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+#endif
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
+{
+    __shared__ float s_box[4][6];
+    __shared__ int s_rect[4][4];
+    __shared__ uint32_t s_cnt[4];
+    __shared__ uint16_t s_list[4][SUB];
+    __shared__ float s_shadow[SH_CAP];
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
+    // every XCD one contiguous run of tiles; horizontally adjacent tiles, which share
+    // 128-byte G-buffer lines, then hit the same L2.
+    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
+    uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, qn = n_tiles >> 3, rn = n_tiles & 7u;
+    uint32_t tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+    const uint32_t tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t x = txi * TILE + (tid & 15u), y = tyi * TILE + (tid >> 4);
+    const bool inb = x < p.width && y < p.height;
+    uint32_t u1 = 0, u2 = 0, u3 = 0;
+    float depth = 1.0f;
+    if (inb) {
+        size_t i = (size_t)y * p.pitch + x;
+        u1 = p.normal[i]; u2 = p.albedo[i]; u3 = p.rm[i]; depth = p.depth[i];
+    }
+    Px q;
+    setup_pixel(q, p, x, y, u1, u2, u3, depth);
+    const bool lit = inb && (u2 >> 24) != 0;    // occlusion 0 => every point-light term is exactly 0
+
+    // ---- 1. tile AABB (+ shadow rectangle) ----
+    const float INF = __builtin_inff();
+    f3 lo = { lit ? q.P.x : INF, lit ? q.P.y : INF, lit ? q.P.z : INF };
+    f3 hi = { lit ? q.P.x : -INF, lit ? q.P.y : -INF, lit ? q.P.z : -INF };
+    const bool want_box = p.n_point > 0;
+    if (want_box) {
+        lo.x = wave_min(lo.x); lo.y = wave_min(lo.y); lo.z = wave_min(lo.z);
+        hi.x = wave_max(hi.x); hi.y = wave_max(hi.y); hi.z = wave_max(hi.z);
+        if (lane == 0) {
+            s_box[wv][0] = lo.x; s_box[wv][1] = lo.y; s_box[wv][2] = lo.z;
+            s_box[wv][3] = hi.x; s_box[wv][4] = hi.y; s_box[wv][5] = hi.z;
+        }
+    }
+    const bool do_shadow = p.has_shadow && p.n_dir > 0;
+    ShadowTap st = { 0, 0, 0.0f, false };
+    if (do_shadow) {
+        st = shadow_tap(q, p);
+        if (p.shadow_lds) {
+            bool use = st.inside && lit;
+            int x0 = wave_mini(use ? st.tx : 0x7FFFFFFF), x1 = wave_maxi(use ? st.tx : -0x7FFFFFFF);
+            int y0 = wave_mini(use ? st.ty : 0x7FFFFFFF), y1 = wave_maxi(use ? st.ty : -0x7FFFFFFF);
+            if (lane == 0) { s_rect[wv][0] = x0; s_rect[wv][1] = x1; s_rect[wv][2] = y0; s_rect[wv][3] = y1; }
+        }
+    }
+    __syncthreads();
+    if (want_box) {
+        lo.x = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
+        lo.y = fminf(fminf(s_box[0][1], s_box[1][1]), fminf(s_box[2][1], s_box[3][1]));
+        lo.z = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
+        hi.x = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
+        hi.y = fmaxf(fmaxf(s_box[0][4], s_box[1][4]), fmaxf(s_box[2][4], s_box[3][4]));
+        hi.z = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
+    }
+    const bool any_lit = want_box && lo.x <= hi.x;
+
+    // ---- 2. shadow factor, taps from LDS when the tile's texel rectangle fits ----
+    float shadow = 1.0f;
+    if (do_shadow) {
+        bool staged = false;
+        int rx0 = 0, ry0 = 0, rw = 0;
+        if (p.shadow_lds) {
+            int x0 = min(min(s_rect[0][0], s_rect[1][0]), min(s_rect[2][0], s_rect[3][0]));
+            int x1 = max(max(s_rect[0][1], s_rect[1][1]), max(s_rect[2][1], s_rect[3][1]));
+            int y0 = min(min(s_rect[0][2], s_rect[1][2]), min(s_rect[2][2], s_rect[3][2]));
+            int y1 = max(max(s_rect[0][3], s_rect[1][3]), max(s_rect[2][3], s_rect[3][3]));
+            if (x0 <= x1) {
+                rw = x1 - x0 + 3;
+                int rh = y1 - y0 + 3;
+                rx0 = x0 - 1; ry0 = y0 - 1;
+                if ((long long)rw * rh <= SH_CAP) {
+                    staged = true;
+                    const int S = (int)p.shadow_size;
+                    for (int yy = (int)(tid >> 4); yy < rh; yy += 16) {
+                        int sy = min(max(ry0 + yy, 0), S - 1);      // clamp-to-edge baked into the staged copy
+                        for (int xx = (int)(tid & 15u); xx < rw; xx += 16) {
+                            int sx = min(max(rx0 + xx, 0), S - 1);
+                            s_shadow[yy * rw + xx] = p.shadow_map[(size_t)sy * S + sx];
+                        }
+                    }
+                }
+            }
+            __syncthreads();   // uniform: every thread of the block takes the p.shadow_lds branch
+        }
+        if (staged) {
+            if (st.inside && lit) {
+                int cnt = 0, bx = st.tx - rx0, by = st.ty - ry0;
+#pragma unroll
+                for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; dx++) cnt += (st.zc <= s_shadow[(by + dy) * rw + bx + dx]) ? 1 : 0;
+                shadow = pcf_result(cnt);
+            }
+        } else if (lit) {
+            shadow = pcf_direct(st, p);
+        }
+    }
+
+    // ---- directional lights first, in index order (fs_deferred_lighting.glsl:62-64) ----
+    f3 res = { 0.0f, 0.0f, 0.0f };
+    for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, p, l, shadow, do_shadow && l == 0, res);
+
+    // ---- 3/4. point lights: cull a chunk into LDS, shade it, next chunk ----
+    uint32_t total = 0;
+    if (any_lit) {
+        for (uint32_t base = 0; base < p.n_point; base += CHUNK) {
+            uint32_t cnt = 0;
+            const uint32_t wbase = base + wv * SUB;
+            for (uint32_t j = 0; j < SUB; j += 64) {
+                uint32_t li = wbase + j + lane;
+                if (wbase + j >= p.n_point) break;      // wave-uniform
+                bool pass = false;
+                if (li < p.n_point) {
+#if MIL_STRICT
+                    v4f a = ((const v4f *)p.point_raw)[2 * li];
+#else
+                    v4f a = ((const v4f *)p.point_prep)[2 * li];
+#endif
+                    pass = box_d2(a, lo, hi) < point_r2(a);
+                }
+                unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) {
+                    uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s_list[wv][pos] = (uint16_t)(li - base);
+                }
+                cnt += (uint32_t)__builtin_popcountll(m);
+            }
+            if (lane == 0) s_cnt[wv] = cnt;
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t w = 0; w < 4; w++) {
+                const uint32_t n = s_cnt[w];
+                total += n;
+#pragma unroll 1
+                for (uint32_t k = 0; k < n; k++) {
+                    uint32_t li = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[w][k]);
+                    add_point(q, p, li, res);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (p.tile_counts && tid == 0) p.tile_counts[tile] = total;
+    if (p.has_ambient) add_ambient(q, p, res);
+    if (inb) store_pixel<FMT>(p, x, y, res);
+}
+
+// ---------------------------------------------------------------------------------
+// K4: tonemap + pack (fs_tonemap.glsl:23-27).  Block = 64 x 4 pixels.
+// ---------------------------------------------------------------------------------
+template <int FMT>
+__global__ __launch_bounds__(256) void k_tonemap(const TonemapParams p)
+{
+    uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.width || y >= p.height) return;
+    v4f h = __builtin_nontemporal_load((const v4f *)p.hdr + (size_t)y * p.hdr_pitch + x);
+    __builtin_nontemporal_store(encode_ldr<FMT>(h.x, h.y, h.z, p.lut11, p.lut10), p.out + (size_t)y * p.out_pitch + x);
+}
+
+#if !MIL_STRICT
+// Brute-force count of in-radius (pixel, point light) pairs: the FLOP-roofline denominator.
+__global__ __launch_bounds__(256) void k_count_pairs(const ShadeParams p, unsigned long long *count)
+{
+    uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    unsigned long long n = 0;
+    if (x < p.width && y < p.height) {
+        size_t i = (size_t)y * p.pitch + x;
+        Px q;
+        setup_pixel(q, p, x, y, p.normal[i], p.albedo[i], p.rm[i], p.depth[i]);
+        if (q.occ > 0.0f)
+            for (uint32_t l = 0; l < p.n_point; l++) {
+                v4f a = ldu(p.point_prep, 2 * l);
+                f3 Lv;
+                n += point_d2(q, a, Lv) < a.w ? 1u : 0u;
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if (((threadIdx.y * 64 + threadIdx.x) & 63u) == 0 && n) atomicAdd(count, n);
+}
+#endif
+
+// ---------------------------------------------------------------------------------
+// launchers (host)
+// ---------------------------------------------------------------------------------
+void launch_stream(int fmt, const ShadeParams &p, hipStream_t s)
+{
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    switch (fmt) {
+    case FMT_HDR: hipLaunchKernelGGL(k_stream<FMT_HDR>, grid, block, 0, s, p); break;
+    case FMT_LDR: hipLaunchKernelGGL(k_stream<FMT_LDR>, grid, block, 0, s, p); break;
+    case FMT_SRGB8: hipLaunchKernelGGL(k_stream<FMT_SRGB8>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_stream<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
+    }
+}
+void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s)
+{
+    dim3 block(256), grid(p.tiles_x * p.tiles_y);
+    switch (fmt) {
+    case FMT_HDR: hipLaunchKernelGGL(k_tiled<FMT_HDR>, grid, block, 0, s, p); break;
+    case FMT_LDR: hipLaunchKernelGGL(k_tiled<FMT_LDR>, grid, block, 0, s, p); break;
+    case FMT_SRGB8: hipLaunchKernelGGL(k_tiled<FMT_SRGB8>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_tiled<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
+    }
+}
+void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
+{
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    switch (fmt) {
+    case FMT_LDR: hipLaunchKernelGGL(k_tonemap<FMT_LDR>, grid, block, 0, s, p); break;
+    case FMT_SRGB8: hipLaunchKernelGGL(k_tonemap<FMT_SRGB8>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL(k_tonemap<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
+    }
+}
+#if !MIL_STRICT
+void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)
+{
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    hipLaunchKernelGGL(k_count_pairs, grid, block, 0, s, p, count);
+}
+#endif
+
+} // namespace MIL_NS
+} // namespace mil

@@ -1,0 +1,61 @@
+// Kernel-argument block shared by the host runtime (mil_api.cpp) and the two
+// device translation units (mil_fast.hip / mil_strict.hip).  Passed BY VALUE in the
+// kernarg segment: the 272-byte FrameMatrixData and the 12-byte push constants of
+// the reference draw (render/mod.rs:201-216) never need a device-side copy.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mil {
+
+struct ShadeParams {
+    // G-buffer planes (device), see mil_gbuffer
+    const uint32_t *normal, *albedo, *rm;
+    const float *depth;
+    uint32_t width, height, pitch, y_offset;
+    // FrameMatrixData subset read by the lighting shader (fs_deferred_lighting.glsl:34-36,59)
+    float inv_proj[16], inv_view[16], cam[3];
+    float res_x, res_y;     // push_constants.resolution
+    float sx, ox, sy, oy;   // fast path: clip.xy = (x, y_global) * s + o  ==  ((x+0.5)/res)*2-1
+    // staged light arrays (device): each record = 2 float4
+    uint32_t n_dir, n_point;
+    const float4 *dir_raw;    // {direction.xyz, intensity} {color.xyz, pad}               (strict)
+    const float4 *dir_prep;   // {direction.xyz, 0} {color.xyz * intensity, 0}             (fast)
+    const float4 *point_raw;  // {position.xyz, radius} {color.xyz, intensity}             (strict)
+    const float4 *point_prep; // {position.xyz, radius^2} {color.xyz * intensity, 1/r^2}   (fast + culling)
+    float ambient[3];
+    uint32_t has_ambient;
+    // shadow extension
+    uint32_t has_shadow, shadow_size, shadow_lds;
+    float shadow_bias;
+    float lvp[16];
+    const float *shadow_map;
+    // output
+    void *out;
+    uint32_t out_pitch;
+    uint32_t tiles_x, tiles_y;
+    uint32_t *tile_counts;      // optional per-tile list length (diagnostics)
+    const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
+};
+
+struct TonemapParams {
+    const float4 *hdr;
+    uint32_t *out;
+    uint32_t width, height, hdr_pitch, out_pitch;
+    const uint8_t *lut11, *lut10;
+};
+
+// implemented once per numeric mode
+namespace fast {
+void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
+void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
+void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
+void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
+}
+namespace strict {
+void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
+void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
+void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
+}
+
+} // namespace mil

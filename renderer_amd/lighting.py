@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference's lighting + tonemap subpasses over libmil.so.
+
+The reference records these two draws inline in ``Frame::build``
+(/root/reference/renderer/src/render/mod.rs:189-219 and :296-309); the bindings of
+those draws (set 0 FrameMatrixData, set 1 the four G-buffer input attachments, set 2
+Lights, push constants; render/mod.rs:26-29, pbr/mod.rs:207-229) are the arguments
+here.  All work runs in hand-written HIP behind the C ABI of include/mil.h; torch is
+only the owner of device memory and streams.  There is no CPU fallback: importing
+works without a GPU, calling does not.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import ubo
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmil.so')
+
+OUT_HDR, OUT_LDR, OUT_SRGB8, OUT_SRGB8_VIA_LDR = 0, 1, 2, 3
+FLAG_STRICT, FLAG_NO_CULL, FLAG_SHADOW_DIRECT = 1, 2, 4
+TILE = 16
+
+EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
+           'mil_set_tile_count_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
+           'mil_light_ex', 'mil_count_pairs']
+
+
+class MilError(RuntimeError):
+    pass
+
+
+class GBuffer(ctypes.Structure):           # mil_gbuffer
+    _fields_ = [('normal_l_model', ctypes.c_void_p), ('albedo_occlusion', ctypes.c_void_p),
+                ('roughness_metallic', ctypes.c_void_p), ('depth', ctypes.c_void_p),
+                ('width', ctypes.c_uint32), ('height', ctypes.c_uint32),
+                ('pitch_px', ctypes.c_uint32), ('y_offset', ctypes.c_uint32)]
+
+
+class Shadow(ctypes.Structure):            # mil_shadow
+    _fields_ = [('light_view_proj', ctypes.c_float * 16), ('map', ctypes.c_void_p),
+                ('size', ctypes.c_uint32), ('bias', ctypes.c_float)]
+
+
+class Extras(ctypes.Structure):            # mil_extras
+    _fields_ = [('point_lights', ctypes.c_void_p), ('n_point', ctypes.c_uint32),
+                ('ambient', ctypes.c_float * 3), ('shadow', ctypes.POINTER(Shadow))]
+
+
+_lib = None
+
+
+def load_library(path=LIB_PATH):
+    """dlopen libmil.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise MilError(f'{path} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           f'(hipcc --offload-arch=gfx950); there is no CPU fallback')
+        # torch ships its own libamdhip64.so.7; load it FIRST so libmil.so (NEEDED
+        # libamdhip64.so.7) binds to that same runtime instance.  Streams and device pointers
+        # handed across the C ABI are only meaningful inside one HIP runtime.
+        import torch  # noqa: F401
+        lib = ctypes.CDLL(path)
+        lib.mil_strerror.restype = ctypes.c_char_p
+        lib.mil_strerror.argtypes = [ctypes.c_int]
+        lib.mil_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint32]
+        lib.mil_destroy.argtypes = [ctypes.c_void_p]
+        lib.mil_destroy.restype = None
+        lib.mil_last_hip_error.argtypes = [ctypes.c_void_p]
+        lib.mil_set_tile_count_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.mil_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        vp, u32 = ctypes.c_void_p, ctypes.c_uint32
+        lib.mil_light_directional.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, vp, u32, u32, vp]
+        lib.mil_tonemap.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_int, u32, vp]
+        lib.mil_light_ex.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras), vp, u32,
+                                     ctypes.c_int, u32, vp]
+        lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
+        _lib = lib
+    return _lib
+
+
+def _np_ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+class LightingPass:
+    """One mil_ctx on one GPU.  ``gb`` arguments are the plane dicts of
+    ``renderer_amd.synth`` (int32/float32 CUDA tensors + width/height/y_offset)."""
+
+    def __init__(self, device=0, max_point_lights=4096):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise MilError('no HIP device visible: the lighting pass has no CPU fallback')
+        self.device = torch.device('cuda', device)
+        h = ctypes.c_void_p()
+        self._check(self.lib.mil_create(ctypes.byref(h), device, max_point_lights), None)
+        self.ctx = h
+
+    def close(self):
+        if getattr(self, 'ctx', None):
+            self.lib.mil_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    def _check(self, rc, ctx='self'):
+        if rc != 0:
+            hip = self.lib.mil_last_hip_error(self.ctx) if ctx == 'self' and getattr(self, 'ctx', None) else 0
+            raise MilError(f'mil error {rc}: {self.lib.mil_strerror(rc).decode()} (hip {hip})')
+
+    def _stream(self, stream):
+        s = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        return ctypes.c_void_p(s.cuda_stream)
+
+    def _gb(self, gb):
+        d = gb['depth']
+        assert d.is_cuda and d.dtype == self.torch.float32 and d.stride(1) == 1
+        for k in ('normal', 'albedo_occ', 'rough_metal'):
+            assert gb[k].is_cuda and gb[k].dtype == self.torch.int32 and gb[k].stride() == d.stride(), k
+        h, w = d.shape
+        return GBuffer(gb['normal'].data_ptr(), gb['albedo_occ'].data_ptr(), gb['rough_metal'].data_ptr(),
+                       d.data_ptr(), w, h, d.stride(0), gb.get('y_offset', 0))
+
+    @staticmethod
+    def _push(gb, n_dir):
+        h, w = gb['depth'].shape
+        return ubo.push_constants(gb.get('width', w), gb.get('height', h), n_dir)
+
+    def light_directional(self, gb, frame, lights, out=None, strict=False, stream=None):
+        """The lighting draw (render/mod.rs:201-216): returns hdr (h, w, 4) float32."""
+        t = self.torch
+        h, w = gb['depth'].shape
+        lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 8)
+        frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+        push = self._push(gb, lights.shape[0])
+        if out is None:
+            out = t.empty((h, w, 4), dtype=t.float32, device=self.device)
+        g = self._gb(gb)
+        self._check(self.lib.mil_light_directional(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights),
+                                                   _np_ptr(push), out.data_ptr(), out.stride(0) // 4,
+                                                   FLAG_STRICT if strict else 0, self._stream(stream)))
+        return out
+
+    def tonemap(self, hdr, fmt=OUT_LDR, out=None, strict=False, stream=None):
+        """The tonemap draw (render/mod.rs:297-309): returns (h, w) int32 holding the packed u32."""
+        t = self.torch
+        h, w = hdr.shape[:2]
+        if out is None:
+            out = t.empty((h, w), dtype=t.int32, device=self.device)
+        self._check(self.lib.mil_tonemap(self.ctx, hdr.data_ptr(), hdr.stride(0) // 4, w, h, out.data_ptr(),
+                                         out.stride(0), fmt, FLAG_STRICT if strict else 0, self._stream(stream)))
+        return out
+
+    def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,
+                 flags=0, out=None, stream=None):
+        """Lighting with the build-defined extensions, optionally fused with the tonemap."""
+        t = self.torch
+        h, w = gb['depth'].shape
+        lights = np.ascontiguousarray(lights if lights is not None else np.zeros((0, 8)), np.float32).reshape(-1, 8)
+        frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+        push = self._push(gb, lights.shape[0])
+        ex = Extras()
+        keep = []
+        if point_lights is not None and len(point_lights):
+            pl = np.ascontiguousarray(point_lights, np.float32).reshape(-1, 8)
+            keep.append(pl)
+            ex.point_lights, ex.n_point = pl.ctypes.data, pl.shape[0]
+        if ambient is not None:
+            ex.ambient = (ctypes.c_float * 3)(*[float(a) for a in ambient])
+        if shadow is not None:
+            sm = shadow['map']
+            assert sm.is_cuda and sm.dtype == t.float32 and sm.is_contiguous() and sm.shape[0] == sm.shape[1]
+            sh = Shadow((ctypes.c_float * 16)(*[float(v) for v in shadow['light_view_proj']]), sm.data_ptr(),
+                        sm.shape[0], float(shadow['bias']))
+            keep.append(sh)
+            ex.shadow = ctypes.pointer(sh)
+        if out is None:
+            out = (t.empty((h, w, 4), dtype=t.float32, device=self.device) if fmt == OUT_HDR
+                   else t.empty((h, w), dtype=t.int32, device=self.device))
+        pitch = out.stride(0) // 4 if fmt == OUT_HDR else out.stride(0)
+        g = self._gb(gb)
+        self._check(self.lib.mil_light_ex(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
+                                          ctypes.byref(ex), out.data_ptr(), pitch, fmt, flags, self._stream(stream)))
+        return out
+
+    def count_pairs(self, gb, frame, point_lights, stream=None):
+        t = self.torch
+        pl = np.ascontiguousarray(point_lights, np.float32).reshape(-1, 8)
+        frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+        push = self._push(gb, 0)
+        cnt = t.zeros(1, dtype=t.int64, device=self.device)
+        g = self._gb(gb)
+        self._check(self.lib.mil_count_pairs(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(push), _np_ptr(pl),
+                                             pl.shape[0], cnt.data_ptr(), self._stream(stream)))
+        return int(cnt.item())
+
+    def tile_counts(self, gb, enable=True):
+        """Diagnostics: returns a (tiles_y, tiles_x) int32 tensor the next culled call fills."""
+        t = self.torch
+        h, w = gb['depth'].shape
+        buf = t.zeros(((h + TILE - 1) // TILE, (w + TILE - 1) // TILE), dtype=t.int32, device=self.device)
+        self._check(self.lib.mil_set_tile_count_buffer(self.ctx, buf.data_ptr() if enable else None))
+        return buf
+
+    def sync(self, stream=None):
+        self._check(self.lib.mil_sync(self.ctx, self._stream(stream)))
