@@ -289,6 +289,7 @@ DEV void shadow_coords(const Px &q, const ShadeParams &p, float &u, float &v, fl
 DEV float pcf_result(int cnt) { return (float)cnt * (1.0f / 9.0f); }
 DEV float aces1(float x)
 {
+    x = fminf(x, 1.0e9f);   // ACESFilm is 1 (clamped) far below this; keeps x*x finite and 1/den normal
     float num = x * __builtin_fmaf(2.51f, x, 0.03f), den = __builtin_fmaf(x, __builtin_fmaf(2.43f, x, 0.59f), 0.14f);
     return clampf(num * rcp_(den), 0.0f, 1.0f);
 }

@@ -1,0 +1,65 @@
+"""CPU-side checks of the drop-in boundary: libmil.so loads, exports every symbol that
+include/mil.h declares, and the uniform structs have the reference's std140 sizes.  No
+compute call is made here (no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from renderer_amd import lighting, ubo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'mil.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(mil_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_symbols_are_exported():
+    lib = lighting.load_library()
+    syms = declared_symbols()
+    assert sorted(syms) == sorted(lighting.EXPORTS)
+    for s in syms:
+        assert hasattr(lib, s), s
+    assert lib.mil_version() == 1
+    assert lib.mil_strerror(0) == b'ok' and b'bad argument' in lib.mil_strerror(-1)
+
+
+def test_struct_layouts_match_reference():
+    # mil_gbuffer / mil_shadow / mil_extras as the ctypes mirror sees them
+    assert ctypes.sizeof(lighting.GBuffer) == 48
+    assert ctypes.sizeof(lighting.Shadow) == 80
+    assert ctypes.sizeof(lighting.Extras) == 32
+    # reference blocks (render/ubo.rs:28-63, fs_deferred_lighting.glsl:16-27)
+    assert ubo.frame_matrix_data(np.eye(4), np.eye(4), (1, 2, 3)).nbytes == ubo.FRAME_UBO_BYTES == 272
+    f = ubo.frame_matrix_data(np.eye(4), np.eye(4), (1, 2, 3))
+    assert list(f[64:68]) == [1, 2, 3, 0]          # cameraPosition @256, 4 B pad
+    assert ubo.default_directional_lights().itemsize * 8 == ubo.LIGHT_STRIDE_BYTES == 32
+    assert ubo.push_constants(3840, 2160, 1).tobytes() == np.array([3840, 2160], np.float32).tobytes() + b'\x01\0\0\0'
+
+
+def test_calls_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(lighting.MilError):
+        lighting.LightingPass(0)
+    # the C ABI itself reports the missing device instead of aborting
+    lib = lighting.load_library()
+    h = ctypes.c_void_p()
+    assert lib.mil_create(ctypes.byref(h), 0, 16) == -4 and not h.value
+    assert lib.mil_create(None, 0, 16) == -1
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under renderer_amd/ may import, link or load it."""
+    pkg = os.path.join(ROOT, 'renderer_amd')
+    pat = re.compile(r'^\s*(from|import)\s+oracle\b|libmil_oracle|coracle|#include\s+".*oracle', re.M)
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(('.py', '.cpp', '.hpp', '.hip', '.h')) or fn == 'Makefile':
+                assert not pat.search(open(os.path.join(dirpath, fn)).read()), fn

@@ -1,0 +1,331 @@
+"""GPU parity tests: the HIP path (through the C ABI of include/mil.h) against the CPU
+oracles on the same seeded inputs.
+
+Bars:
+  * strict mode (MIL_FLAG_STRICT): BIT-EXACT against oracle/mil_oracle.c (FP32, GLSL
+    operator order) for HDR, R11G11B10F and the LUT-based sRGB8 path;
+  * fast mode (default): |a-b| <= 1e-3 + 1e-4*|b| in linear HDR against the float64
+    oracle (BASELINE.md / north_star), widened only by the conditioning term
+    8*2^-24*cond where the reference's own D_GGX is ill-conditioned in FP32, and <= 1 LSB
+    after tonemap + sRGB8; PCF is a discrete test, so with shadows on at most 0.1 % of the
+    pixels may differ by one tap;
+  * integer / index work (culling, strips, fused-vs-unfused) bit-exact in both modes.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mil_oracle as mo
+from renderer_amd import lighting, synth, ubo
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = 'cuda:0'
+AMB = (0.03, 0.03, 0.03)
+
+
+@pytest.fixture(scope='module')
+def lp():
+    p = lighting.LightingPass(0, max_point_lights=4096)
+    yield p
+    p.close()
+
+
+def planes_np(gb):
+    g = synth.to_numpy(gb)
+    return g['normal'], g['albedo_occ'], g['rough_metal'], g['depth']
+
+
+def make_scene(kind, w, h, n_point=0, shadow=0, seed=0x5EED0000):
+    cam = synth.sweep_camera(w, h)
+    gb = synth.scene_sweep(w, h, cam, device=DEV) if kind == 'sweep' else synth.scene_noise(w, h, seed, device=DEV)
+    frame = cam.frame_matrix_data()
+    dl = ubo.default_directional_lights()
+    pl = synth.point_light_field(n_point, seed + 1) if n_point else None
+    sh = synth.shadow_setup(dl[0, 0:3], shadow, device=DEV) if shadow else None
+    return gb, frame, dl, pl, sh
+
+
+def sh_np(sh):
+    return None if sh is None else dict(sh, map=sh['map'].cpu().numpy())
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_bits_equal(a, b, what=''):
+    a, b = bits(a), bits(b)
+    if not np.array_equal(a, b):
+        bad = np.argwhere(a != b)
+        raise AssertionError(f'{what}: {len(bad)} words differ, first at {bad[0]}')
+
+
+def fast_tolerance_ok(gpu, planes, frame, dl, pl=None, amb=None, sh=None, y_offset=0, full_height=None,
+                      max_bad_frac=0.0):
+    ref, cond = mo.shade(*planes, frame, dl, point_lights=pl, ambient=amb, shadow=sh, want_cond=True,
+                         y_offset=y_offset, full_height=full_height)
+    tol = 1e-3 + 1e-4 * np.abs(ref[..., :3]) + 8 * 2.0 ** -24 * cond
+    err = np.abs(gpu[..., :3].astype(np.float64) - ref[..., :3])
+    bad = (err > tol) | ~np.isfinite(gpu[..., :3])
+    frac = bad.any(-1).mean()
+    assert frac <= max_bad_frac, f'{bad.any(-1).sum()} pixels outside tolerance (max err {err.max():.3g})'
+    assert np.all(gpu[..., 3] == 1.0)
+    return ref
+
+
+# ------------------------------------------------------------------ K1: the reference path
+@pytest.mark.parametrize('kind,w,h', [('sweep', 320, 180), ('noise', 256, 144), ('sweep', 67, 35)])
+def test_k1_directional_strict_bit_exact(lp, coracle, kind, w, h):
+    gb, frame, dl, _, _ = make_scene(kind, w, h)
+    out = lp.light_directional(gb, frame, dl, strict=True).cpu().numpy()
+    assert_bits_equal(out, coracle.shade(*planes_np(gb), frame, dl), 'K1 strict vs C oracle')
+
+
+@pytest.mark.parametrize('kind,w,h', [('sweep', 320, 180), ('noise', 256, 144)])
+def test_k1_directional_fast_tolerance(lp, kind, w, h):
+    gb, frame, dl, _, _ = make_scene(kind, w, h)
+    out = lp.light_directional(gb, frame, dl).cpu().numpy()
+    fast_tolerance_ok(out, planes_np(gb), frame, dl)
+
+
+def test_k1_many_lights_and_limits(lp, coracle):
+    gb, frame, _, _, _ = make_scene('sweep', 96, 54)
+    rng = np.random.RandomState(5)
+    d = rng.randn(100, 3)
+    d[:, 1] = np.abs(d[:, 1])
+    dl = ubo.directional_lights([(d[i], 0.05 + rng.rand(), 0.3 + 0.7 * rng.rand(3)) for i in range(100)])
+    out = lp.light_directional(gb, frame, dl, strict=True).cpu().numpy()      # MAX_LIGHTS = 100 (inc_structs.glsl:1)
+    assert_bits_equal(out, coracle.shade(*planes_np(gb), frame, dl), '100 lights')
+    fast_tolerance_ok(lp.light_directional(gb, frame, dl).cpu().numpy(), planes_np(gb), frame, dl)
+    with pytest.raises(lighting.MilError, match='-2'):                      # the reference panics at 101 (render/mod.rs:197-199)
+        lp.light_directional(gb, frame, np.concatenate([dl, dl[:1]]))
+    zero = lp.light_directional(gb, frame, dl[:0]).cpu().numpy()            # light_count = 0
+    assert np.all(zero[..., :3] == 0) and np.all(zero[..., 3] == 1)
+
+
+def test_background_and_cleared_gbuffer(lp):
+    w, h = 80, 48
+    z = torch.zeros((h, w), dtype=torch.int32, device=DEV)
+    gb = dict(normal=z, albedo_occ=z, rough_metal=z, depth=torch.ones((h, w), device=DEV), width=w, height=h, y_offset=0)
+    frame = synth.sweep_camera(w, h).frame_matrix_data()
+    for strict in (False, True):
+        out = lp.light_directional(gb, frame, ubo.default_directional_lights(), strict=strict).cpu().numpy()
+        assert np.all(out[..., :3] == 0) and np.all(out[..., 3] == 1)       # render/mod.rs:129-133 clear values -> 0, not NaN
+
+
+def test_ragged_sizes_and_pitch(lp, coracle):
+    for (w, h) in [(1, 1), (17, 5), (64, 4), (65, 5), (130, 33)]:
+        gb, frame, dl, pl, sh = make_scene('noise', w, h, n_point=9, shadow=32, seed=w * 131 + h)
+        ref = coracle.shade(*planes_np(gb), frame, dl)
+        assert_bits_equal(lp.light_directional(gb, frame, dl, strict=True).cpu().numpy(), ref, f'{w}x{h}')
+        ref = coracle.shade(*planes_np(gb), frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh))
+        assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_STRICT).cpu().numpy(), ref, f'ex {w}x{h}')
+    # planes that are views into wider allocations (pitch_px > width), output likewise
+    w, h, pitch = 50, 20, 64
+    big, frame, dl, _, _ = make_scene('noise', pitch, h, seed=77)
+    gb = {k: (v[:, 3:3 + w] if torch.is_tensor(v) else v) for k, v in big.items()}
+    gb.update(width=w, height=h)
+    outbuf = torch.full((h, pitch, 4), -7.0, device=DEV)
+    out = lp.light_directional(gb, frame, dl, out=outbuf[:, 5:5 + w], strict=True)
+    gbc = {k: (v.contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()}
+    assert_bits_equal(out.cpu().numpy(), coracle.shade(*planes_np(gbc), frame, dl), 'pitched')
+    assert torch.all(outbuf[:, :5] == -7.0) and torch.all(outbuf[:, 5 + w:] == -7.0)
+
+
+def test_bad_arguments_return_status(lp):
+    lib = lp.lib
+    gb, frame, dl, _, _ = make_scene('noise', 32, 16)
+    g = lp._gb(gb)
+    push = ubo.push_constants(32, 16, 2)
+    out = torch.empty((16, 32, 4), device=DEV)
+    fp = lambda a: ctypes.c_void_p(a.ctypes.data)
+    assert lib.mil_light_directional(lp.ctx, None, fp(frame), fp(dl), fp(push), out.data_ptr(), 32, 0, None) == -1
+    assert lib.mil_light_directional(lp.ctx, ctypes.byref(g), fp(frame), fp(dl), fp(push), None, 32, 0, None) == -1
+    assert lib.mil_light_directional(lp.ctx, ctypes.byref(g), fp(frame), fp(dl), fp(push), out.data_ptr(), 31, 0, None) == -1
+    g2 = lp._gb(gb)
+    g2.pitch_px = 8
+    assert lib.mil_light_directional(lp.ctx, ctypes.byref(g2), fp(frame), fp(dl), fp(push), out.data_ptr(), 32, 0, None) == -1
+    small = lighting.LightingPass(0, max_point_lights=4)
+    with pytest.raises(lighting.MilError, match='-5'):
+        small.light_ex(gb, frame, dl, synth.point_light_field(5, 1))
+    small.close()
+    assert lib.mil_tonemap(lp.ctx, out.data_ptr(), 32, 32, 16, out.data_ptr(), 32, 0, 0, None) == -1   # HDR is not a tonemap target
+
+
+# ------------------------------------------------------------------ K4: tonemap / pack
+def hdr_samples(n=64):
+    rng = np.random.RandomState(3)
+    a = np.concatenate([rng.rand(n, n, 4) * 8, rng.rand(n, n, 4) * 0.02, rng.rand(n, n, 4) * 3e-5,
+                        10.0 ** rng.uniform(-8, 6, (n, n, 4))], 0).astype(np.float32)
+    a[0, 0] = [0, 1, 10, 1]
+    a[0, 1] = [1e30, 1e19, 65504, 1]        # x*x overflows FP32: see test_k4_tonemap_fast_tolerance
+    return a
+
+
+def channels(u):
+    return np.stack([(u >> s) & 0xFF for s in (0, 8, 16, 24)], -1).astype(int)
+
+
+def test_k4_tonemap_strict_bit_exact(lp, coracle):
+    hdr = hdr_samples()
+    t = torch.from_numpy(hdr).to(DEV)
+    for fmt in (lighting.OUT_LDR, lighting.OUT_SRGB8_VIA_LDR):
+        out = lp.tonemap(t, fmt, strict=True).cpu().numpy().view(np.uint32)
+        np.testing.assert_array_equal(out, coracle.tonemap(hdr, fmt))
+    out = lp.tonemap(t, lighting.OUT_SRGB8, strict=True).cpu().numpy().view(np.uint32)
+    assert np.abs(channels(out) - channels(coracle.tonemap(hdr, 2))).max() <= 1     # float powf vs double pow
+
+
+def test_k4_tonemap_fast_tolerance(lp, coracle):
+    hdr = hdr_samples()
+    t = torch.from_numpy(hdr).to(DEV)
+    ref = mo.tonemap(hdr, mo.OUT_LDR)
+    out = lp.tonemap(t, lighting.OUT_LDR).cpu().numpy().view(np.uint32)
+    # pixel (0,1): x*x overflows FP32 above ~1.8e19.  Strict mode reproduces the literal FP32 result
+    # (inf/inf = NaN -> clamp -> 0, test above); fast mode saturates x first and agrees with float64 (1.0).
+    d = out != ref
+    assert d.mean() < 2e-3                                                   # rounding-boundary straddles only ...
+    step = np.abs(np.stack([(out & 0x7FF).astype(int) - (ref & 0x7FF), ((out >> 11) & 0x7FF).astype(int) - ((ref >> 11) & 0x7FF),
+                            (out >> 22).astype(int) - (ref >> 22)], -1))
+    assert step.max() <= 1                                                   # ... and never more than one code
+    out8 = lp.tonemap(t, lighting.OUT_SRGB8).cpu().numpy().view(np.uint32)
+    ref8 = mo.tonemap(hdr, mo.OUT_SRGB8)
+    assert np.abs(channels(out8) - channels(ref8)).max() <= 1               # <= 1 LSB after 8-bit tonemap
+    assert np.all(channels(out8)[..., 3] == 255)
+
+
+@pytest.mark.parametrize('strict', [False, True])
+def test_fused_equals_unfused(lp, strict):
+    gb, frame, dl, pl, sh = make_scene('sweep', 200, 120, n_point=40, shadow=128)
+    fl = lighting.FLAG_STRICT if strict else 0
+    hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=fl)
+    for fmt in (lighting.OUT_LDR, lighting.OUT_SRGB8, lighting.OUT_SRGB8_VIA_LDR):
+        fused = lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=fmt, flags=fl)
+        assert torch.equal(fused, lp.tonemap(hdr, fmt, strict=strict)), fmt
+        fused = lp.light_ex(gb, frame, dl, fmt=fmt, flags=fl)                # streaming kernel, reference path only
+        assert torch.equal(fused, lp.tonemap(lp.light_directional(gb, frame, dl, strict=strict), fmt, strict=strict)), fmt
+
+
+# ------------------------------------------------------------------ extensions E1-E4
+@pytest.mark.parametrize('kind,w,h,n_point', [('sweep', 320, 180, 64), ('noise', 128, 72, 24), ('sweep', 96, 54, 1500)])
+def test_extensions_strict_bit_exact(lp, coracle, kind, w, h, n_point):
+    gb, frame, dl, pl, sh = make_scene(kind, w, h, n_point=n_point, shadow=256)
+    ref = coracle.shade(*planes_np(gb), frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh))
+    S = lighting.FLAG_STRICT
+    for fl in (S, S | lighting.FLAG_NO_CULL, S | lighting.FLAG_SHADOW_DIRECT, S | lighting.FLAG_NO_CULL | lighting.FLAG_SHADOW_DIRECT):
+        assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=fl).cpu().numpy(), ref, f'flags {fl}')
+
+
+def test_golden_fixtures_on_gpu(lp):
+    for name in ('sweep_96x54', 'noise_64x36'):
+        z = np.load(os.path.join(GOLDEN, name + '.npz'))
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).view(dt)).to(DEV)
+        h, w = z['depth'].shape
+        gb = dict(normal=t(z['normal'], np.int32), albedo_occ=t(z['albedo_occ'], np.int32),
+                  rough_metal=t(z['rough_metal'], np.int32), depth=t(z['depth'], np.float32), width=w, height=h, y_offset=0)
+        sh = dict(light_view_proj=z['shadow_lvp'], map=t(z['shadow_map'], np.float32), bias=float(z['shadow_bias']))
+        S = lighting.FLAG_STRICT
+        assert_bits_equal(lp.light_directional(gb, z['frame'], z['dir_lights'], strict=True).cpu().numpy(), z['hdr_dir_only_c32'], name)
+        hdr = lp.light_ex(gb, z['frame'], z['dir_lights'], z['point_lights'], z['ambient'], sh, flags=S)
+        assert_bits_equal(hdr.cpu().numpy(), z['hdr_c32'], name)
+        np.testing.assert_array_equal(lp.tonemap(hdr, lighting.OUT_LDR, strict=True).cpu().numpy().view(np.uint32), z['ldr_c32'])
+        np.testing.assert_array_equal(lp.tonemap(hdr, lighting.OUT_SRGB8_VIA_LDR, strict=True).cpu().numpy().view(np.uint32), z['srgb8_via_ldr_c32'])
+        fast = lp.light_ex(gb, z['frame'], z['dir_lights'], z['point_lights'], z['ambient'], sh).cpu().numpy()
+        tol = 1e-3 + 1e-4 * np.abs(z['hdr_f64']) + 1e-3 * np.abs(z['hdr_f64']) * (name.startswith('noise'))
+        assert (np.abs(fast - z['hdr_f64']) > tol).any(-1).mean() < 5e-3
+
+
+@pytest.mark.parametrize('kind,w,h', [('sweep', 320, 180), ('noise', 128, 72)])
+def test_extensions_fast_tolerance(lp, kind, w, h):
+    gb, frame, dl, pl, sh = make_scene(kind, w, h, n_point=64, shadow=256)
+    out = lp.light_ex(gb, frame, dl, pl, AMB, None).cpu().numpy()
+    fast_tolerance_ok(out, planes_np(gb), frame, dl, pl, AMB, None)
+    out = lp.light_ex(gb, frame, dl, pl, AMB, sh).cpu().numpy()            # PCF is discrete: allow rare one-tap flips
+    ref = fast_tolerance_ok(out, planes_np(gb), frame, dl, pl, AMB, sh_np(sh), max_bad_frac=1e-3)
+    srgb = lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_SRGB8).cpu().numpy().view(np.uint32)
+    d = np.abs(channels(srgb) - channels(mo.tonemap(ref, mo.OUT_SRGB8))).max(-1)
+    assert (d > 1).mean() <= 1e-3                                            # <= 1 LSB after 8-bit tonemap (tap flips aside)
+
+
+@pytest.mark.parametrize('strict', [False, True])
+def test_culled_equals_brute_force(lp, strict):
+    """Tile lists keep ascending light order, so culling never changes a bit."""
+    fl = lighting.FLAG_STRICT if strict else 0
+    for kind, w, h, n in [('sweep', 320, 180, 256), ('sweep', 100, 60, 2500), ('noise', 64, 48, 300)]:
+        gb, frame, dl, pl, _ = make_scene(kind, w, h, n_point=n)
+        counts = lp.tile_counts(gb)
+        a = lp.light_ex(gb, frame, dl, pl, flags=fl)
+        lp.tile_counts(gb, enable=False)
+        b = lp.light_ex(gb, frame, dl, pl, flags=fl | lighting.FLAG_NO_CULL)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (kind, n)
+        if kind == 'sweep':
+            assert 0 < counts.float().mean().item() < 0.6 * n                # the culling does cull
+
+
+@pytest.mark.parametrize('strict', [False, True])
+def test_extensions_vanish_when_disabled(lp, strict):
+    gb, frame, dl, _, _ = make_scene('sweep', 160, 90)
+    fl = lighting.FLAG_STRICT if strict else 0
+    a = lp.light_directional(gb, frame, dl, strict=strict)
+    b = lp.light_ex(gb, frame, dl, None, (0, 0, 0), None, flags=fl)
+    c = lp.light_ex(gb, frame, dl, synth.point_light_field(16, 3) * np.array([1, 1, 1, 0, 1, 1, 1, 1], np.float32), flags=fl)  # radius 0
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32)) and torch.equal(a.view(torch.int32), c.view(torch.int32))
+
+
+@pytest.mark.parametrize('strict', [False, True])
+def test_strips_equal_monolithic(lp, strict):
+    """Strip-sharded == monolithic, bit for bit: global y via y_offset."""
+    w, h = 256, 144
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=48, shadow=128)
+    fl = lighting.FLAG_STRICT if strict else 0
+    full = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=fl)
+    for bounds in ([0, 48, 96, 144], [0, 37, 101, 144]):
+        for y0, y1 in zip(bounds[:-1], bounds[1:]):
+            strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+            strip['y_offset'] = y0
+            part = lp.light_ex(strip, frame, dl, pl, AMB, sh, flags=fl)
+            assert torch.equal(part.view(torch.int32), full[y0:y1].view(torch.int32)), (y0, y1)
+            gen = synth.scene_sweep(w, h, synth.sweep_camera(w, h), device=DEV, rows=(y0, y1))   # generator agrees too
+            assert torch.equal(gen['depth'], gb['depth'][y0:y1]) and torch.equal(gen['normal'], gb['normal'][y0:y1])
+
+
+def test_count_pairs(lp, coracle):
+    gb, frame, dl, pl, _ = make_scene('sweep', 160, 90, n_point=100)
+    _, pairs = coracle.shade(*planes_np(gb), frame, dl[:0], point_lights=pl, return_pairs=True)
+    got = lp.count_pairs(gb, frame, pl)
+    assert abs(got - pairs) <= max(2, 1e-4 * pairs)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE.json sizes)
+def test_4k_properties(lp):
+    w, h = 3840, 2160
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=256, shadow=2048)
+    a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    b = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL | lighting.FLAG_SHADOW_DIRECT)
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))             # culled + LDS-staged == brute force + direct
+    assert torch.isfinite(a).all() and torch.all(a[..., 3] == 1)
+    # strips at 16-row-aligned cuts (2160 = 7*272 + 256)
+    cuts = [0] + [272 * i for i in range(1, 8)] + [h]
+    for y0, y1 in zip(cuts[:-1], cuts[1:]):
+        strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+        strip['y_offset'] = y0
+        part = lp.light_ex(strip, frame, dl, pl, AMB, sh)
+        assert torch.equal(part.view(torch.int32), a[y0:y1].view(torch.int32))
+    # linearity in the light set (HDR, no shadow): shade(l0) + shade(l1) == shade(l0, l1) to rounding
+    s0, s1 = lp.light_directional(gb, frame, dl[:1]), lp.light_directional(gb, frame, dl[1:])
+    s01 = lp.light_directional(gb, frame, dl)
+    err = (s0[..., :3] + s1[..., :3] - s01[..., :3]).abs()
+    assert torch.all(err <= 1e-5 * s01[..., :3].abs() + 1e-6)
+    # fused packed output == unfused
+    ldr = lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_LDR)
+    assert torch.equal(ldr, lp.tonemap(a, lighting.OUT_LDR))
+    # oracle spot-check on a 16-row band through the sphere wall
+    y0, y1 = 1000, 1016
+    strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+    strip['y_offset'] = y0
+    fast_tolerance_ok(a[y0:y1].cpu().numpy(), planes_np(strip), frame, dl, pl, AMB, sh_np(sh), y_offset=y0,
+                      full_height=h, max_bad_frac=1e-3)
