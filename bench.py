@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X lighting pass on BASELINE.json's headline configuration.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one 3840x2160 synthetic G-buffer (Scene A, SURVEY.md
+8d): the lighting kernel (2 directional lights of main.rs:80-91, light 0 with 2048^2 3x3-PCF
+shadow, 256 point lights culled per 16x16 tile into LDS lists, ambient) writing the
+RGBA32F hdr attachment, then the fused tonemap/gamma kernel (ACES + sRGB8).  Inputs are
+resident in HBM before the timed region; three buffer sets (> 256 MiB) rotate so the
+Infinity Cache cannot hold a frame.  N > 1: frame-parallel (each rank shades its own frame
+of an orbiting camera) with an overlapped grouped-P2P gather of the packed frames to GPU 0;
+per-GPU work is fixed, so scaling is "weak".  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak
+# Algorithmic FLOP constants frozen in SURVEY.md 8(d)
+C_PIX, C_DIR_MIN, C_POINT_MIN = 75, 80, 100
+
+WORKLOADS = {
+    # name: (width, height, n_dir, n_point, shadow_size, ambient)
+    'headline': (3840, 2160, 2, 256, 2048, True),
+    'k1_1light': (3840, 2160, 1, 0, 0, False),
+    'cfg2_1080p': (1920, 1080, 1, 0, 2048, False),
+    'cfg4_8k': (7680, 4320, 2, 4096, 2048, True),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='headline', choices=sorted(WORKLOADS))
+    ap.add_argument('--sets', type=int, default=3, help='rotating buffer sets (cold-cache protocol)')
+    ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-extra', action='store_true', help='skip the 4K/1-light HBM-bound side measurement')
+    ap.add_argument('--fused', action='store_true', help='one kernel: lighting + tonemap -> sRGB8 (20 B/px)')
+    ap.add_argument('--flags', type=int, default=0, help='extra MIL_FLAG_* bits (experiments)')
+    return ap.parse_args()
+
+
+def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64):
+    from renderer_amd import sharding
+    w, h, n_dir, n_point, shadow_size, ambient = WORKLOADS[wl]
+    cam = synth.sweep_camera(w, h) if frame_idx is None else sharding.orbit_camera(frame_idx, n_frames, w, h)
+    gb0 = synth.scene_sweep(w, h, cam, device=device)
+    sets = [gb0] + [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in gb0.items()} for _ in range(n_sets - 1)]
+    dl = ubo.default_directional_lights()[:n_dir]
+    pl = synth.point_light_field(n_point, 0x5EED0003) if n_point else None
+    sh = synth.shadow_setup(dl[0, 0:3], shadow_size, device=device) if shadow_size else None
+    amb = (0.03, 0.03, 0.03) if ambient else None
+    return dict(w=w, h=h, cam=cam, frame=cam.frame_matrix_data(), sets=sets, dl=dl, pl=pl, sh=sh, amb=amb,
+                n_dir=n_dir, n_point=n_point, shadow_size=shadow_size)
+
+
+def algorithmic(inp, pairs, fused):
+    """Per-launch algorithmic bytes and FLOPs of the lighting kernel."""
+    px = inp['w'] * inp['h']
+    bytes_ = px * (16 + (4 if fused else 16)) + 32 * (inp['n_dir'] + inp['n_point']) + 272
+    if inp['shadow_size']:
+        bytes_ += inp['shadow_size'] ** 2 * 4
+    flops = px * C_PIX + px * inp['n_dir'] * C_DIR_MIN + pairs * C_POINT_MIN
+    return bytes_, flops
+
+
+def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0):
+    """Returns (seconds for `steps` steps [max over ranks], mean ms of the lighting kernel, mean ms tonemap)."""
+    from renderer_amd import sharding
+    dev = lp.device
+    n_sets = len(inp['sets'])
+    w, h = inp['w'], inp['h']
+    hdr = [None if fused else torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    out = [torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
+    slots = [[torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(n_sets)] \
+        if (world > 1 and rank == 0) else [None] * n_sets
+    pending = [[] for _ in range(n_sets)]
+
+    def step(i, ev=None):
+        s = i % n_sets
+        for q in pending[s]:          # the set's previous gather must be done before its buffers are rewritten
+            q.wait()
+        pending[s] = []
+        gb = inp['sets'][s]
+        if ev:
+            ev[0].record()
+        if fused:
+            lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_SRGB8,
+                        flags=flags, out=out[s])
+            if ev:
+                ev[1].record()
+        else:
+            lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_HDR,
+                        flags=flags, out=hdr[s])
+            if ev:
+                ev[1].record()
+            lp.tonemap(hdr[s], lighting.OUT_SRGB8, out=out[s])
+            if ev:
+                ev[2].record()
+        if world > 1:
+            pending[s] = sharding.gather_frames(out[s], slots[s], dst=0, async_op=True)
+
+    def drain():
+        for s in range(n_sets):
+            for q in pending[s]:
+                q.wait()
+            pending[s] = []
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        step(i)
+    drain()
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+    if dist is not None and world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warmup + i, events[i])
+    drain()
+    if dist is not None and world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    light_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
+    tone_ms = 0.0 if fused else float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
+    dt = t1 - t0
+    if dist is not None and world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, light_ms, tone_ms
+
+
+def cpu_baseline(inp, target_s=12.0):
+    """The FP32 C restatement (oracle/mil_oracle.c, "port") on a bounded band of rows of the same
+    workload, all host threads OpenMP gives us.  Reported beside the GPU number, not a target."""
+    from oracle import coracle
+    from renderer_amd import synth
+    coracle.build()
+    threads = coracle.max_threads()
+    w, h = inp['w'], inp['h']
+    sh = None if inp['sh'] is None else dict(inp['sh'], map=inp['sh']['map'].cpu().numpy())
+
+    def run(rows):
+        y0 = h // 2 - rows // 2          # band through the sphere wall
+        strip = {k: (v[y0:y0 + rows].cpu() if hasattr(v, 'cpu') else v) for k, v in inp['sets'][0].items()}
+        g = synth.to_numpy(strip)
+        t0 = time.perf_counter()
+        hdr = coracle.shade(g['normal'], g['albedo_occ'], g['rough_metal'], g['depth'], inp['frame'], inp['dl'],
+                            point_lights=inp['pl'], ambient=inp['amb'], shadow=sh, y_offset=y0, full_height=h,
+                            nthreads=threads)
+        coracle.tonemap(hdr, 2, nthreads=threads)
+        return time.perf_counter() - t0
+
+    rows = 16
+    t = run(rows)
+    rows_full = int(min(h, max(rows, rows * target_s / max(t, 1e-6)))) // 16 * 16
+    if rows_full > rows:
+        rows, t = rows_full, run(rows_full)
+    return dict(value=round(rows * w / t / 1e6, 4), unit='Mpix/s', cores=threads, kind='port',
+                sample=f'{rows} of {h} rows x {w} px (band centred on the sphere wall), same lights/shadow/ambient, '
+                       f'lighting + tonemap, {t:.1f} s wall, oracle/mil_oracle.c brute-force over all lights')
+
+
+def main():
+    args = parse()
+    import torch
+    from renderer_amd import lighting, synth, ubo
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
+                     '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
+        args.gpus = world
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = f'cuda:{local_rank}'
+
+    lp = lighting.LightingPass(local_rank, max_point_lights=4096)
+    inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, frame_idx=(rank if world > 1 else None))
+    px = inp['w'] * inp['h']
+    pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if inp['pl'] is not None else 0
+
+    dt, light_ms, tone_ms = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags,
+                                         dist, world, rank)
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    abytes, aflops = algorithmic(inp, pairs, args.fused)
+    hbm = abytes / (light_ms * 1e-3) / 1e9
+    valu = aflops / (light_ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    kname = 'k_tiled' if (inp['n_point'] or inp['shadow_size']) else 'k_stream'
+    if os.path.exists(tpath):
+        t = json.load(open(tpath)).get(f'{args.workload}{"_fused" if args.fused else ""}:{kname}')
+        if t:
+            traffic = t['hbm_bytes_per_launch']
+    roof_hbm = dict(bound='hbm', achieved=round(hbm, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm / HBM_PEAK_GBS, 4),
+                    traffic=traffic, kernel=kname, ms=round(light_ms, 4), algorithmic_bytes=abytes)
+    roof_valu = dict(bound='valu', achieved=round(valu, 2), peak=VALU_PEAK_TFLOPS, unit='TFLOP/s',
+                     frac=round(valu / VALU_PEAK_TFLOPS, 4), traffic=traffic, kernel=kname, ms=round(light_ms, 4),
+                     algorithmic_flops=aflops, pairs_in_radius=pairs)
+    # the binding roofline is the one the kernel sits closer to
+    primary, other = (roof_hbm, roof_valu) if roof_hbm['frac'] >= roof_valu['frac'] else (roof_valu, roof_hbm)
+
+    res = dict(metric='shaded Mpix/s at 3840x2160, 256 point lights + PCF shadows; % HBM/VALU roofline',
+               value=round(world * args.steps * px / dt / 1e6, 1), unit='Mpix/s', n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling='weak',
+               vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload=f'{args.workload}: {inp["w"]}x{inp["h"]} Scene A sweep, {inp["n_dir"]} directional '
+                                    f'(light 0 PCF {inp["shadow_size"]}^2) + {inp["n_point"]} point lights'
+                                    + (' + ambient' if inp['amb'] else ''),
+                           kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
+                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else f'frame-parallel x{world} + P2P gather to GPU 0'),
+                           tonemap_ms=round(tone_ms, 4)),
+               roofline=primary, roofline_other=other)
+
+    if not args.no_extra and world == 1 and args.workload == 'headline':
+        # side measurement: the HBM-bound 4K / 1-light lighting pass (BASELINE.md target >= 70 % of HBM roofline)
+        inp1 = build_inputs(torch, synth, ubo, 'k1_1light', dev, args.sets)
+        _, l1, _ = run_workload(torch, lighting, lp, inp1, args.steps, args.warmup, False, 0)
+        b1, f1 = algorithmic(inp1, 0, False)
+        res['extra'] = {'k1_4k_1light': dict(kernel='k_stream -> hdr RGBA32F', ms=round(l1, 4), mpix_s=round(px / l1 / 1e3, 1),
+                                             hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
+                                             algorithmic_bytes=b1)}
+        del inp1
+    if not args.no_cpu and world == 1:
+        res['cpu_baseline'] = cpu_baseline(inp)
+    print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

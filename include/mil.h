@@ -116,7 +116,8 @@ typedef enum mil_out_format {
 enum {
     MIL_FLAG_STRICT = 1u << 0,      /* GLSL operator order, IEEE div/sqrt, no FMA contraction: bit-exact vs the CPU oracle */
     MIL_FLAG_NO_CULL = 1u << 1,     /* point lights by brute force (every light, every pixel) */
-    MIL_FLAG_SHADOW_DIRECT = 1u << 2 /* PCF taps straight from global memory (no LDS staging) */
+    MIL_FLAG_SHADOW_LDS = 1u << 2   /* stage each tile's shadow-map rectangle in LDS and tap it there (default: taps
+                                       straight from global memory through L1, which measured faster) */
 };
 
 typedef struct mil_extras {

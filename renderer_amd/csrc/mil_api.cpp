@@ -6,6 +6,7 @@
 #include <math.h>
 #include <new>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/mil.h"
@@ -24,8 +25,10 @@ constexpr uint32_t LUT11_N = 0x3C1, LUT10_N = 0x1E1;
 struct Slot {
     uint8_t *host = nullptr; // pinned
     uint8_t *dev = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr;   // last kernel that read this slot
+    hipEvent_t staged = nullptr; // upload of this slot's content finished (recorded on the copy stream)
     bool used = false;
+    uint32_t n_dir = 0, n_point = 0;
 };
 
 } // namespace
@@ -35,9 +38,13 @@ struct mil_ctx {
     uint32_t max_point = 0;
     size_t slot_bytes = 0;
     Slot ring[RING];
-    int next = 0;
+    int next = 0, cur = -1;      // cur: slot holding the most recently staged content
+    uint8_t *scratch = nullptr;  // host: the content of this call, built before it is compared with slot `cur`
+    hipStream_t copy_stream = nullptr;
     uint8_t *lut = nullptr; // device: lut11 then lut10
     uint32_t *tile_counts = nullptr;
+    uint32_t tune = 0;
+    uint32_t k1_rows = 1;   // K1 pixels per lane: 1 or 4 (env MIL_K1_ROWS overrides; tuning only)
     int last_hip = 0;
 };
 
@@ -86,17 +93,20 @@ int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push)
     return MIL_OK;
 }
 
-// Stage the light arrays into the next ring slot and fill the light part of ShadeParams.
-// Layout per slot: dir_raw | dir_prep | point_raw | point_prep, each n x 32 bytes.
+// Stage the light arrays and fill the light part of ShadeParams.
+// Layout per slot: dir_raw | dir_prep | point_raw | point_prep (n x 32 bytes each) | point_cull (n x 16).
+// The content is built on the host first; when it equals what the current slot already holds
+// (static lights, the common case frame to frame) nothing is uploaded.  Otherwise the next ring
+// slot is filled and uploaded on the context's copy stream, so the upload overlaps whatever the
+// caller's stream is still running, and the caller's stream waits on the slot's `staged` event.
 int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, const mil_point_light *pl,
-                 uint32_t n_point, hipStream_t s, mil::ShadeParams &p, Slot *&slot_out)
+                 uint32_t n_point, bool strict, hipStream_t s, mil::ShadeParams &p, Slot *&slot_out)
 {
-    Slot &sl = c->ring[c->next];
-    c->next = (c->next + 1) % RING;
-    if (sl.used) HIP_TRY(c, hipEventSynchronize(sl.done)); // slot still in flight from RING calls ago
     const size_t dir_b = (size_t)MIL_MAX_DIR_LIGHTS * 32, pt_b = (size_t)c->max_point * 32;
-    float *h_dir_raw = (float *)sl.host, *h_dir_prep = (float *)(sl.host + dir_b);
-    float *h_pt_raw = (float *)(sl.host + 2 * dir_b), *h_pt_prep = (float *)(sl.host + 2 * dir_b + pt_b);
+    uint8_t *h = c->scratch;
+    float *h_dir_raw = (float *)h, *h_dir_prep = (float *)(h + dir_b);
+    float *h_pt_raw = (float *)(h + 2 * dir_b), *h_pt_prep = (float *)(h + 2 * dir_b + pt_b);
+    float *h_pt_cull = (float *)(h + 2 * dir_b + 2 * pt_b);
     for (uint32_t i = 0; i < n_dir; i++) {
         const mil_directional_light &l = dl[i];
         float *r = h_dir_raw + 8 * i, *q = h_dir_prep + 8 * i;
@@ -113,17 +123,51 @@ int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, co
         q[0] = l.position[0]; q[1] = l.position[1]; q[2] = l.position[2]; q[3] = r2;
         q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity;
         q[7] = 1.0f / r2;
+        float *k = h_pt_cull + 4 * i;
+        k[0] = l.position[0]; k[1] = l.position[1]; k[2] = l.position[2]; k[3] = l.radius;
     }
-    if (n_dir) HIP_TRY(c, hipMemcpyAsync(sl.dev, sl.host, 2 * dir_b, hipMemcpyHostToDevice, s));
-    if (n_point)
-        HIP_TRY(c, hipMemcpyAsync(sl.dev + 2 * dir_b, sl.host + 2 * dir_b, 2 * pt_b, hipMemcpyHostToDevice, s));
+    for (uint32_t i = 0; i < n_dir && i < MIL_DIR_INLINE; i++)
+        memcpy(p.dir_inline[i], (strict ? h_dir_raw : h_dir_prep) + 8 * i, 32);
+
+    // the first MIL_DIR_INLINE directional records travel in the kernarg; a device copy is needed
+    // only beyond that, or for point lights
+    const bool need_dev = n_dir > MIL_DIR_INLINE || n_point > 0;
+    Slot *sl = nullptr;
+    if (need_dev) {
+        const size_t nd = (size_t)n_dir * 32, np = (size_t)n_point * 32;
+        if (c->cur >= 0) {
+            Slot &cs = c->ring[c->cur];
+            if (cs.n_dir == n_dir && cs.n_point == n_point && !memcmp(cs.host, h, nd) && !memcmp(cs.host + dir_b, h + dir_b, nd) &&
+                !memcmp(cs.host + 2 * dir_b, h + 2 * dir_b, np) && !memcmp(cs.host + 2 * dir_b + pt_b, h + 2 * dir_b + pt_b, np) &&
+                !memcmp(cs.host + 2 * dir_b + 2 * pt_b, h + 2 * dir_b + 2 * pt_b, np / 2))
+                sl = &cs;
+        }
+        if (!sl) {
+            c->cur = c->next;
+            sl = &c->ring[c->next];
+            c->next = (c->next + 1) % RING;
+            if (sl->used) HIP_TRY(c, hipEventSynchronize(sl->done)); // kernels of RING contents ago may still read it
+            if (nd) { memcpy(sl->host, h, nd); memcpy(sl->host + dir_b, h + dir_b, nd); }
+            if (np) {
+                memcpy(sl->host + 2 * dir_b, h + 2 * dir_b, np);
+                memcpy(sl->host + 2 * dir_b + pt_b, h + 2 * dir_b + pt_b, np);
+                memcpy(sl->host + 2 * dir_b + 2 * pt_b, h + 2 * dir_b + 2 * pt_b, np / 2);
+            }
+            sl->n_dir = n_dir; sl->n_point = n_point;
+            if (nd) HIP_TRY(c, hipMemcpyAsync(sl->dev, sl->host, dir_b + nd, hipMemcpyHostToDevice, c->copy_stream));
+            if (np) HIP_TRY(c, hipMemcpyAsync(sl->dev + 2 * dir_b, sl->host + 2 * dir_b, 2 * pt_b + np / 2, hipMemcpyHostToDevice, c->copy_stream));
+            HIP_TRY(c, hipEventRecord(sl->staged, c->copy_stream));
+        }
+        HIP_TRY(c, hipStreamWaitEvent(s, sl->staged, 0));
+        p.dir_raw = (const float4 *)sl->dev;
+        p.dir_prep = (const float4 *)(sl->dev + dir_b);
+        p.point_raw = (const float4 *)(sl->dev + 2 * dir_b);
+        p.point_prep = (const float4 *)(sl->dev + 2 * dir_b + pt_b);
+        p.point_cull = (const float4 *)(sl->dev + 2 * dir_b + 2 * pt_b);
+    }
     p.n_dir = n_dir;
     p.n_point = n_point;
-    p.dir_raw = (const float4 *)sl.dev;
-    p.dir_prep = (const float4 *)(sl.dev + dir_b);
-    p.point_raw = (const float4 *)(sl.dev + 2 * dir_b);
-    p.point_prep = (const float4 *)(sl.dev + 2 * dir_b + pt_b);
-    slot_out = &sl;
+    slot_out = sl;
     return MIL_OK;
 }
 
@@ -183,14 +227,21 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
     if (!c) return MIL_ERR_HIP;
     c->device = device;
     c->max_point = max_point_lights;
-    c->slot_bytes = 2 * ((size_t)MIL_MAX_DIR_LIGHTS * 32 + (size_t)max_point_lights * 32);
+    if (const char *e = getenv("MIL_TUNE")) c->tune = (uint32_t)atoi(e);
+    if (const char *e = getenv("MIL_K1_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->k1_rows = (uint32_t)v; }
+    c->slot_bytes = 2 * (size_t)MIL_MAX_DIR_LIGHTS * 32 + (size_t)max_point_lights * (32 + 32 + 16);
     int rc = set_device(c);
     for (int i = 0; rc == MIL_OK && i < RING; i++) {
         Slot &s = c->ring[i];
         if (hipHostMalloc((void **)&s.host, c->slot_bytes, hipHostMallocDefault) != hipSuccess ||
             hipMalloc((void **)&s.dev, c->slot_bytes) != hipSuccess ||
-            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)
+            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.staged, hipEventDisableTiming) != hipSuccess)
             rc = MIL_ERR_HIP;
+    }
+    if (rc == MIL_OK) {
+        c->scratch = (uint8_t *)malloc(c->slot_bytes);
+        if (!c->scratch || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MIL_ERR_HIP;
     }
     if (rc == MIL_OK) {
         uint8_t h[LUT11_N + LUT10_N];
@@ -213,12 +264,15 @@ void mil_destroy(mil_ctx *c)
     if (!c) return;
     set_device(c);
     for (Slot &s : c->ring) {
-        if (s.used) hipEventSynchronize(s.done);
-        if (s.done) hipEventDestroy(s.done);
-        if (s.host) hipHostFree(s.host);
-        if (s.dev) hipFree(s.dev);
+        if (s.used) (void)hipEventSynchronize(s.done);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.staged) (void)hipEventDestroy(s.staged);
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.dev) (void)hipFree(s.dev);
     }
-    if (c->lut) hipFree(c->lut);
+    if (c->lut) (void)hipFree(c->lut);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    free(c->scratch);
     delete c;
 }
 
@@ -258,8 +312,10 @@ int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     hipStream_t s = (hipStream_t)stream;
     mil::ShadeParams p;
     fill_common(p, gb, frame, push);
+    p.rows_per_block = c->k1_rows;
+    p.tune = c->tune;
     Slot *slot = nullptr;
-    if ((rc = stage_lights(c, lights, push->light_count, ex ? ex->point_lights : nullptr, n_point, s, p, slot))) return rc;
+    if ((rc = stage_lights(c, lights, push->light_count, ex ? ex->point_lights : nullptr, n_point, (flags & MIL_FLAG_STRICT) != 0, s, p, slot))) return rc;
     if (ex && (ex->ambient[0] != 0.0f || ex->ambient[1] != 0.0f || ex->ambient[2] != 0.0f)) {
         p.has_ambient = 1;
         memcpy(p.ambient, ex->ambient, 12);
@@ -269,7 +325,7 @@ int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
         p.shadow_size = sh->size;
         p.shadow_bias = sh->bias;
         p.shadow_map = sh->map;
-        p.shadow_lds = (flags & MIL_FLAG_SHADOW_DIRECT) ? 0u : 1u;
+        p.shadow_lds = (flags & MIL_FLAG_SHADOW_LDS) ? 1u : 0u;
         memcpy(p.lvp, sh->light_view_proj, 64);
     }
     p.out = out;
@@ -328,7 +384,7 @@ int mil_count_pairs(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_da
     mil::ShadeParams p;
     fill_common(p, gb, frame, push);
     Slot *slot = nullptr;
-    if ((rc = stage_lights(c, nullptr, 0, pl, n_point, s, p, slot))) return rc;
+    if ((rc = stage_lights(c, nullptr, 0, pl, n_point, false, s, p, slot))) return rc;
     HIP_TRY(c, hipMemsetAsync(count, 0, sizeof(unsigned long long), s));
     mil::fast::launch_count_pairs(p, count, s);
     return finish(c, slot, s);

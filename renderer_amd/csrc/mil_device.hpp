@@ -26,9 +26,9 @@ namespace MIL_NS {
 
 constexpr float PI_LIT = 3.14159f;   // inc_brdf.glsl:6,46 (literal, not pi)
 constexpr int TILE = 16;
-constexpr int CHUNK = 1024;          // point lights culled per LDS pass (4 waves x 256)
-constexpr int SUB = CHUNK / 4;
-constexpr int SH_CAP = 4096;         // floats of shadow map staged in LDS per tile (16 KiB)
+constexpr uint32_t DIR_INLINE = MIL_DIR_INLINE;
+constexpr int CHUNK = 1024;          // point lights culled per LDS pass (u16 list, 2 KiB per wave)
+constexpr int SH_CAP = 576;          // floats of shadow map staged in LDS per wave/tile (24x24 texels, 2.25 KiB)
 
 enum { FMT_HDR = 0, FMT_LDR = 1, FMT_SRGB8 = 2, FMT_SRGB8_VIA_LDR = 3 };
 
@@ -41,6 +41,26 @@ DEV float sat(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 // uniform (wave-invariant) fetch of a staged light record through the scalar cache
 typedef const __attribute__((address_space(4))) v4f *cptr4;
 DEV v4f ldu(const float4 *p, uint32_t i) { return ((cptr4)(uintptr_t)p)[i]; }
+
+// Directional light record l in this mode's layout (mil_params.h).  The first DIR_INLINE
+// records travel in the kernarg segment itself, so the common 1-4 light frame needs no
+// dependent pointer chase before its first BRDF evaluation.
+struct DirRec { v4f a, b; };
+DEV DirRec dir_rec(const ShadeParams &p, uint32_t l)
+{
+    DirRec d;
+    if (l < DIR_INLINE) {
+        const float *r = p.dir_inline[l];
+        d.a = v4f{ r[0], r[1], r[2], r[3] }; d.b = v4f{ r[4], r[5], r[6], r[7] };
+    } else {
+#if MIL_STRICT
+        d.a = ldu(p.dir_raw, 2 * l); d.b = ldu(p.dir_raw, 2 * l + 1);
+#else
+        d.a = ldu(p.dir_prep, 2 * l); d.b = ldu(p.dir_prep, 2 * l + 1);
+#endif
+    }
+    return d;
+}
 
 // ---------------------------------------------------------------------------------
 // per-pixel state
@@ -55,7 +75,6 @@ struct Px {
     float alpha, a2, am1, NdotV, sV;   // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
     f3 F0, dF;                         // dF = f90 - F0
     f3 dif, tint;                      // albedo/PI*(1-m)*occ ; ((1-m) + albedo*m)*occ
-    f3 albocc;                         // albedo*occ (ambient)
 #endif
 };
 
@@ -72,7 +91,18 @@ DEV float mrow(const float *m, int r, float x, float y, float z, float w)
     return ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
 }
 
-DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth)
+// PositionFromDepth, fs_deferred_lighting.glsl:30-38 (y is the strip-local row)
+DEV f3 pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+{
+    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
+    float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
+    float vx = mrow(p.inv_proj, 0, px, py, depth, 1.0f), vy = mrow(p.inv_proj, 1, px, py, depth, 1.0f);
+    float vz = mrow(p.inv_proj, 2, px, py, depth, 1.0f), vw = mrow(p.inv_proj, 3, px, py, depth, 1.0f);
+    vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
+    return f3{ mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
+}
+
+DEV void setup_pixel(Px &q, const ShadeParams &p, f3 P, uint32_t u1, uint32_t u2, uint32_t u3)
 {
     f3 b1 = { (float)(u1 & 0x3FF) / 1023.0f, (float)((u1 >> 10) & 0x3FF) / 1023.0f, (float)((u1 >> 20) & 0x3FF) / 1023.0f };
     q.albedo = f3{ (float)(u2 & 0xFF) / 255.0f, (float)((u2 >> 8) & 0xFF) / 255.0f, (float)((u2 >> 16) & 0xFF) / 255.0f };
@@ -80,13 +110,7 @@ DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32
     float roughness = clampf((float)(u3 & 0xFF) / 255.0f, 0.0001f, 1.0f);     // fs_deferred_lighting.glsl:51
     q.metallic = (float)((u3 >> 8) & 0xFF) / 255.0f;
     f3 nrm = { b1.x * 2.0f - 1.0f, b1.y * 2.0f - 1.0f, b1.z * 2.0f - 1.0f };  // :48
-    // PositionFromDepth :30-38
-    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
-    float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
-    float vx = mrow(p.inv_proj, 0, px, py, depth, 1.0f), vy = mrow(p.inv_proj, 1, px, py, depth, 1.0f);
-    float vz = mrow(p.inv_proj, 2, px, py, depth, 1.0f), vw = mrow(p.inv_proj, 3, px, py, depth, 1.0f);
-    vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
-    q.P = f3{ mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
+    q.P = P;
     q.alpha = roughness * roughness;                                         // :56
     q.N = normalize3(nrm);                                                   // :58
     q.V = normalize3(f3{ p.cam[0] - q.P.x, p.cam[1] - q.P.y, p.cam[2] - q.P.z }); // :59
@@ -123,9 +147,9 @@ DEV f3 brdf_light(const Px &q, f3 L, f3 lightColor)
     return f3{ (color.x * lightColor.x) * NdotL, (color.y * lightColor.y) * NdotL, (color.z * lightColor.z) * NdotL };
 }
 
-DEV void add_directional(const Px &q, const ShadeParams &p, uint32_t l, float shadow, bool use_shadow, f3 &res)
+DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
 {
-    v4f a = ldu(p.dir_raw, 2 * l), b = ldu(p.dir_raw, 2 * l + 1);
+    const v4f a = d.a, b = d.b;
     f3 c = brdf_light(q, f3{ a.x, a.y, a.z }, f3{ b.x, b.y, b.z });
     float ax = (c.x * a.w) * q.occ, ay = (c.y * a.w) * q.occ, az = (c.z * a.w) * q.occ;  // fs_deferred_lighting.glsl:63
     if (use_shadow) { ax = ax * shadow; ay = ay * shadow; az = az * shadow; }
@@ -139,9 +163,10 @@ DEV float point_d2(const Px &q, v4f a, f3 &Lv)
     return dot3(Lv, Lv);
 }
 DEV float point_r2(v4f a) { return a.w * a.w; }
-DEV void add_point(const Px &q, const ShadeParams &p, uint32_t l, f3 &res)
+DEV v4f point_rec_a(const ShadeParams &p, uint32_t l) { return ldu(p.point_raw, 2 * l); }
+DEV v4f point_rec_b(const ShadeParams &p, uint32_t l) { return ldu(p.point_raw, 2 * l + 1); }
+DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
 {
-    v4f a = ldu(p.point_raw, 2 * l), b = ldu(p.point_raw, 2 * l + 1);
     f3 Lv;
     float d2 = point_d2(q, a, Lv), r2 = point_r2(a);
     if (d2 < r2 && q.occ > 0.0f) {
@@ -155,16 +180,16 @@ DEV void add_point(const Px &q, const ShadeParams &p, uint32_t l, f3 &res)
         res.z += ((c.z * b.w) * att) * q.occ;
     }
 }
-DEV void add_ambient(const Px &q, const ShadeParams &p, f3 &res)
+DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t, f3 &res)
 {
     res.x += (p.ambient[0] * q.albedo.x) * q.occ;
     res.y += (p.ambient[1] * q.albedo.y) * q.occ;
     res.z += (p.ambient[2] * q.albedo.z) * q.occ;
 }
-DEV void shadow_coords(const Px &q, const ShadeParams &p, float &u, float &v, float &zr)
+DEV void shadow_coords(f3 P, const ShadeParams &p, float &u, float &v, float &zr)
 {
-    float qx = mrow(p.lvp, 0, q.P.x, q.P.y, q.P.z, 1.0f), qy = mrow(p.lvp, 1, q.P.x, q.P.y, q.P.z, 1.0f);
-    zr = mrow(p.lvp, 2, q.P.x, q.P.y, q.P.z, 1.0f);
+    float qx = mrow(p.lvp, 0, P.x, P.y, P.z, 1.0f), qy = mrow(p.lvp, 1, P.x, P.y, P.z, 1.0f);
+    zr = mrow(p.lvp, 2, P.x, P.y, P.z, 1.0f);
     u = qx * 0.5f + 0.5f; v = qy * 0.5f + 0.5f;
 }
 DEV float pcf_result(int cnt) { return (float)cnt / 9.0f; }
@@ -189,7 +214,17 @@ DEV float mrow1(const float *m, int r, float x, float y, float z)   // w == 1
     return __builtin_fmaf(m[0 + r], x, __builtin_fmaf(m[4 + r], y, __builtin_fmaf(m[8 + r], z, m[12 + r])));
 }
 
-DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth)
+DEV f3 pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+{
+    float px = __builtin_fmaf((float)x, p.sx, p.ox), py = __builtin_fmaf((float)(y + p.y_offset), p.sy, p.oy);
+    float vx = mrow1(p.inv_proj, 0, px, py, depth), vy = mrow1(p.inv_proj, 1, px, py, depth);
+    float vz = mrow1(p.inv_proj, 2, px, py, depth), vw = mrow1(p.inv_proj, 3, px, py, depth);
+    float iw = rcp_(vw);
+    vx *= iw; vy *= iw; vz *= iw;
+    return f3{ mrow1(p.inv_view, 0, vx, vy, vz), mrow1(p.inv_view, 1, vx, vy, vz), mrow1(p.inv_view, 2, vx, vy, vz) };
+}
+
+DEV void setup_pixel(Px &q, const ShadeParams &p, f3 P, uint32_t u1, uint32_t u2, uint32_t u3)
 {
     const float k10 = 2.0f / 1023.0f, k8 = 1.0f / 255.0f;
     f3 nrm = { __builtin_fmaf((float)(u1 & 0x3FF), k10, -1.0f), __builtin_fmaf((float)((u1 >> 10) & 0x3FF), k10, -1.0f),
@@ -198,12 +233,7 @@ DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32
     q.occ = (float)(u2 >> 24) * k8;
     float roughness = fmaxf((float)(u3 & 0xFF) * k8, 0.0001f);
     float m = (float)((u3 >> 8) & 0xFF) * k8;
-    float px = __builtin_fmaf((float)x, p.sx, p.ox), py = __builtin_fmaf((float)(y + p.y_offset), p.sy, p.oy);
-    float vx = mrow1(p.inv_proj, 0, px, py, depth), vy = mrow1(p.inv_proj, 1, px, py, depth);
-    float vz = mrow1(p.inv_proj, 2, px, py, depth), vw = mrow1(p.inv_proj, 3, px, py, depth);
-    float iw = rcp_(vw);
-    vx *= iw; vy *= iw; vz *= iw;
-    q.P = f3{ mrow1(p.inv_view, 0, vx, vy, vz), mrow1(p.inv_view, 1, vx, vy, vz), mrow1(p.inv_view, 2, vx, vy, vz) };
+    q.P = P;
     float rn = rsq_(dot3(nrm, nrm));
     q.N = f3{ nrm.x * rn, nrm.y * rn, nrm.z * rn };
     f3 tc = { p.cam[0] - q.P.x, p.cam[1] - q.P.y, p.cam[2] - q.P.z };
@@ -221,7 +251,6 @@ DEV void setup_pixel(Px &q, const ShadeParams &p, uint32_t x, uint32_t y, uint32
     float ds = om * q.occ * (1.0f / PI_LIT);
     q.dif = f3{ albedo.x * ds, albedo.y * ds, albedo.z * ds };
     q.tint = f3{ __builtin_fmaf(albedo.x, m, om) * q.occ, __builtin_fmaf(albedo.y, m, om) * q.occ, __builtin_fmaf(albedo.z, m, om) * q.occ };
-    q.albocc = f3{ albedo.x * q.occ, albedo.y * q.occ, albedo.z * q.occ };
 }
 
 // light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow]
@@ -245,12 +274,11 @@ DEV void eval_light(const Px &q, f3 L, f3 rad, f3 &res)
     res.z = __builtin_fmaf(cz, rad.z * NdotL, res.z);
 }
 
-DEV void add_directional(const Px &q, const ShadeParams &p, uint32_t l, float shadow, bool use_shadow, f3 &res)
+DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
 {
-    v4f a = ldu(p.dir_prep, 2 * l), b = ldu(p.dir_prep, 2 * l + 1);
-    f3 rad = { b.x, b.y, b.z };
+    f3 rad = { d.b.x, d.b.y, d.b.z };
     if (use_shadow) { rad.x *= shadow; rad.y *= shadow; rad.z *= shadow; }
-    eval_light(q, f3{ a.x, a.y, a.z }, rad, res);
+    eval_light(q, f3{ d.a.x, d.a.y, d.a.z }, rad, res);
 }
 
 DEV float point_d2(const Px &q, v4f a, f3 &Lv)
@@ -259,9 +287,10 @@ DEV float point_d2(const Px &q, v4f a, f3 &Lv)
     return __builtin_fmaf(Lv.z, Lv.z, __builtin_fmaf(Lv.y, Lv.y, Lv.x * Lv.x));
 }
 DEV float point_r2(v4f a) { return a.w; }   // prepared record carries r*r
-DEV void add_point(const Px &q, const ShadeParams &p, uint32_t l, f3 &res)
+DEV v4f point_rec_a(const ShadeParams &p, uint32_t l) { return ldu(p.point_prep, 2 * l); }
+DEV v4f point_rec_b(const ShadeParams &p, uint32_t l) { return ldu(p.point_prep, 2 * l + 1); }
+DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
 {
-    v4f a = ldu(p.point_prep, 2 * l), b = ldu(p.point_prep, 2 * l + 1);
     f3 Lv;
     float d2 = point_d2(q, a, Lv);
     bool on = d2 < a.w && q.occ > 0.0f;
@@ -274,16 +303,17 @@ DEV void add_point(const Px &q, const ShadeParams &p, uint32_t l, f3 &res)
     eval_light(q, L, f3{ b.x * att, b.y * att, b.z * att }, t);
     if (on) { res.x += t.x; res.y += t.y; res.z += t.z; }
 }
-DEV void add_ambient(const Px &q, const ShadeParams &p, f3 &res)
+DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t u2, f3 &res)
 {
-    res.x = __builtin_fmaf(p.ambient[0], q.albocc.x, res.x);
-    res.y = __builtin_fmaf(p.ambient[1], q.albocc.y, res.y);
-    res.z = __builtin_fmaf(p.ambient[2], q.albocc.z, res.z);
+    const float k = q.occ * (1.0f / 255.0f);       // albedo * occlusion re-decoded from the texel
+    res.x = __builtin_fmaf(p.ambient[0], (float)(u2 & 0xFF) * k, res.x);
+    res.y = __builtin_fmaf(p.ambient[1], (float)((u2 >> 8) & 0xFF) * k, res.y);
+    res.z = __builtin_fmaf(p.ambient[2], (float)((u2 >> 16) & 0xFF) * k, res.z);
 }
-DEV void shadow_coords(const Px &q, const ShadeParams &p, float &u, float &v, float &zr)
+DEV void shadow_coords(f3 P, const ShadeParams &p, float &u, float &v, float &zr)
 {
-    float qx = mrow1(p.lvp, 0, q.P.x, q.P.y, q.P.z), qy = mrow1(p.lvp, 1, q.P.x, q.P.y, q.P.z);
-    zr = mrow1(p.lvp, 2, q.P.x, q.P.y, q.P.z);
+    float qx = mrow1(p.lvp, 0, P.x, P.y, P.z), qy = mrow1(p.lvp, 1, P.x, P.y, P.z);
+    zr = mrow1(p.lvp, 2, P.x, P.y, P.z);
     u = __builtin_fmaf(qx, 0.5f, 0.5f); v = __builtin_fmaf(qy, 0.5f, 0.5f);
 }
 DEV float pcf_result(int cnt) { return (float)cnt * (1.0f / 9.0f); }
@@ -306,10 +336,10 @@ DEV uint32_t srgb8_direct(float c)
 // ---------------------------------------------------------------------------------
 struct ShadowTap { int tx, ty; float zc; bool inside; };
 
-DEV ShadowTap shadow_tap(const Px &q, const ShadeParams &p)
+DEV ShadowTap shadow_tap(f3 P, const ShadeParams &p)
 {
     float u, v, zr;
-    shadow_coords(q, p, u, v, zr);
+    shadow_coords(P, p, u, v, zr);
     ShadowTap t;
     t.inside = (u >= 0.0f && u <= 1.0f && v >= 0.0f && v <= 1.0f) && !(zr > 1.0f);
     float S = (float)p.shadow_size;
@@ -372,69 +402,123 @@ DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res)
 }
 
 // ---------------------------------------------------------------------------------
-// K1: streaming kernel.  Block = 64 x 4 pixels; each wave reads one 256-byte row
-// segment per plane and writes one contiguous 1 KiB (HDR) or 256 B (packed) segment.
+// K1: streaming kernel.  Block = 64 x 4 threads covering 64 x 16 pixels; each wave owns a
+// 64-pixel row segment (one 256-byte load per plane, one contiguous 1 KiB HDR store) on four
+// rows, issues all 16 loads first and then shades the four pixels one after the other.
 // Handles directional lights, shadow by direct taps, brute-force point lights, ambient.
 // ---------------------------------------------------------------------------------
-template <int FMT>
-__global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
+template <int FMT, bool EXT>
+DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth, DirRec d0)
 {
-    uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= p.width || y >= p.height) return;
-    size_t i = (size_t)y * p.pitch + x;
-    uint32_t u1 = __builtin_nontemporal_load(p.normal + i), u2 = __builtin_nontemporal_load(p.albedo + i);
-    uint32_t u3 = __builtin_nontemporal_load(p.rm + i);
-    float depth = __builtin_nontemporal_load(p.depth + i);
     Px q;
-    setup_pixel(q, p, x, y, u1, u2, u3, depth);
+    setup_pixel(q, p, pixel_position(p, x, y, depth), u1, u2, u3);
     f3 res = { 0.0f, 0.0f, 0.0f };
     float shadow = 1.0f;
-    if (p.has_shadow && p.n_dir > 0) shadow = pcf_direct(shadow_tap(q, p), p);
-    for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, p, l, shadow, p.has_shadow && l == 0, res);
-    for (uint32_t l = 0; l < p.n_point; l++) add_point(q, p, l, res);
-    if (p.has_ambient) add_ambient(q, p, res);
+    const bool sh = EXT && p.has_shadow;
+    if (sh && p.n_dir > 0) shadow = pcf_direct(shadow_tap(q.P, p), p);
+    DirRec d = d0;
+    for (uint32_t l = 0; l < p.n_dir; l++) {                 // fs_deferred_lighting.glsl:62-64
+        const DirRec dn = dir_rec(p, min(l + 1, p.n_dir - 1)); // next record requested while this one is evaluated
+        add_directional(q, d, shadow, sh && l == 0, res);
+        d = dn;
+    }
+    if (EXT) {
+        for (uint32_t l = 0; l < p.n_point; l++) add_point(q, point_rec_a(p, l), point_rec_b(p, l), res);
+        if (p.has_ambient) add_ambient(q, p, u2, res);
+    }
     store_pixel<FMT>(p, x, y, res);
 }
 
+template <typename T> DEV T sel4(uint32_t j, T a, T b, T c, T d) { return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)); }
+
+template <int FMT, int NPX, bool EXT>
+__global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
+{
+    // Coordinates are clamped for the loads instead of branched around: the texel loads are the
+    // first thing the wave issues (one kernarg fetch away), the bounds test comes afterwards.
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, xc = min(x, p.width - 1), ylast = p.height - 1;
+    if (NPX == 1) {
+        const uint32_t y = blockIdx.y * 4 + threadIdx.y;
+        const size_t i = (size_t)min(y, ylast) * p.pitch + xc;
+        const uint32_t u1 = __builtin_nontemporal_load(p.normal + i), u2 = __builtin_nontemporal_load(p.albedo + i);
+        const uint32_t u3 = __builtin_nontemporal_load(p.rm + i);
+        const float depth = __builtin_nontemporal_load(p.depth + i);
+        const DirRec d0 = dir_rec(p, 0);
+        if (x >= p.width || y > ylast) return;
+        shade_stream_pixel<FMT, EXT>(p, x, y, u1, u2, u3, depth, d0);
+        return;
+    }
+    const uint32_t y0 = blockIdx.y * 16 + threadIdx.y;     // this lane: rows y0, y0+4, y0+8, y0+12
+    uint32_t u1[4], u2[4], u3[4];
+    float dz[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const size_t i = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
+        u1[j] = __builtin_nontemporal_load(p.normal + i); u2[j] = __builtin_nontemporal_load(p.albedo + i);
+        u3[j] = __builtin_nontemporal_load(p.rm + i); dz[j] = __builtin_nontemporal_load(p.depth + i);
+    }
+    const DirRec d0 = dir_rec(p, 0);
+    if (x >= p.width) return;
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t y = y0 + 4 * j;
+        if (y > ylast) break;
+        shade_stream_pixel<FMT, EXT>(p, x, y, sel4(j, u1[0], u1[1], u1[2], u1[3]), sel4(j, u2[0], u2[1], u2[2], u2[3]),
+                                     sel4(j, u3[0], u3[1], u3[2], u3[3]), sel4(j, dz[0], dz[1], dz[2], dz[3]), d0);
+    }
+}
+
 // ---------------------------------------------------------------------------------
-// K2: tiled kernel.  One 256-thread workgroup per 16x16 screen tile.
-//  1. every thread reconstructs its pixel; the tile's world-space AABB of lit pixels
-//     is reduced per wave (cross-lane) and across the 4 waves through LDS;
-//  2. shadow: the tile's texel rectangle (+1 apron) is staged into LDS when it fits;
-//  3. point lights, CHUNK at a time: wave w tests its quarter of the chunk 64 lights
-//     per step against the AABB; survivors are appended to the wave's LDS sub-list
-//     with ballot + prefix popcount, so every list stays in ascending light order and
-//     the sum order equals the brute-force loop's (culled == unculled, bit for bit);
-//  4. all threads walk the four sub-lists, fetching each record through the scalar cache.
+// K2: tiled kernel.  ONE WAVE PER 16x16 SCREEN TILE, no workgroup barrier anywhere: a
+// 256-thread workgroup is four independent waves on four horizontally adjacent tiles (so
+// the workgroup reads whole 256-byte row segments).  Lane l owns pixels
+// (l & 15, (l >> 4) + 4 j), j = 0..3.
+//  1. all 16 texel loads of the lane are issued at once, with the first 64 light records;
+//  2. world positions of the 4 pixels -> the tile's AABB of lit pixels by DPP row
+//     reductions + v_readlane (no LDS round trip);
+//  3. point lights, CHUNK at a time: 64 lights per step are tested against the AABB and
+//     survivors appended to the wave's LDS list with ballot + mbcnt prefix, so the list
+//     stays in ascending light order and the summation order equals the brute-force
+//     loop's (culled == unculled, bit for bit);
+//  4. shadow: when the tile's texel rectangle (+1 apron) fits, the wave stages it in LDS
+//     with clamp-to-edge baked in and the 3x3 taps read LDS;
+//  5. four passes (j) shade 64 pixels each: directional lights, then the LDS list with
+//     light records fetched through the scalar cache one entry ahead.
 // ---------------------------------------------------------------------------------
+template <int CTRL> DEV float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL> DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+// 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x141 row_half_mirror, 0x140 row_mirror:
+// after the four steps every lane holds its 16-lane row's result; rows are combined by readlane.
+DEV float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 DEV float wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, dpp_f<0xB1>(v)); v = fminf(v, dpp_f<0x4E>(v)); v = fminf(v, dpp_f<0x141>(v)); v = fminf(v, dpp_f<0x140>(v));
+    return fminf(fminf(lane_f(v, 0), lane_f(v, 16)), fminf(lane_f(v, 32), lane_f(v, 48)));
 }
 DEV float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v)); v = fmaxf(v, dpp_f<0x140>(v));
+    return fmaxf(fmaxf(lane_f(v, 0), lane_f(v, 16)), fmaxf(lane_f(v, 32), lane_f(v, 48)));
 }
 DEV int wave_mini(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-    return v;
+    v = min(v, dpp_i<0xB1>(v)); v = min(v, dpp_i<0x4E>(v)); v = min(v, dpp_i<0x141>(v)); v = min(v, dpp_i<0x140>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 DEV int wave_maxi(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-    return v;
+    v = max(v, dpp_i<0xB1>(v)); v = max(v, dpp_i<0x4E>(v)); v = max(v, dpp_i<0x141>(v)); v = max(v, dpp_i<0x140>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// squared distance from a light centre to the tile AABB, formed with the same
-// operation sequence as point_d2 so that  pixel in range  =>  box in range  holds
-// exactly under rounding (each step is monotone in |component|).
+// squared distance from a light centre to the tile AABB, formed with the same operation
+// sequence as point_d2 so that  pixel in range  =>  box in range  holds exactly under
+// rounding (every step is monotone in |component|).
 DEV float box_d2(v4f a, f3 lo, f3 hi)
 {
     float dx = fmaxf(fmaxf(lo.x - a.x, a.x - hi.x), 0.0f);
@@ -450,157 +534,170 @@ DEV float box_d2(v4f a, f3 lo, f3 hi)
 template <int FMT>
 __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
 {
-    __shared__ float s_box[4][6];
-    __shared__ int s_rect[4][4];
-    __shared__ uint32_t s_cnt[4];
-    __shared__ uint16_t s_list[4][SUB];
-    __shared__ float s_shadow[SH_CAP];
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    // dynamic LDS: [4 lists: CHUNK u16] [4 result stashes: 3 x 256 f32, only if n_point > CHUNK] [4 shadow rects: SH_CAP f32]
+    const uint32_t n_chunks = p.n_point ? (p.n_point + CHUNK - 1) / CHUNK : 1;
+    const uint32_t wpb = blockDim.x >> 6;               // waves (= tiles) per workgroup
+    uint16_t *s_list = (uint16_t *)s_raw + wv * CHUNK;
+    float *s_res = (float *)(s_raw + wpb * CHUNK * sizeof(uint16_t)) + wv * 768;
+    float *s_shadow = (float *)(s_raw + wpb * CHUNK * sizeof(uint16_t) + (n_chunks > 1 ? wpb * 768 * sizeof(float) : 0)) + wv * SH_CAP;
 
-    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give
-    // every XCD one contiguous run of tiles; horizontally adjacent tiles, which share
-    // 128-byte G-buffer lines, then hit the same L2.
-    const uint32_t n_tiles = p.tiles_x * p.tiles_y;
-    uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3, qn = n_tiles >> 3, rn = n_tiles & 7u;
-    uint32_t tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-    const uint32_t tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
+    // Workgroups keep dispatch (round-robin over XCDs) order: neighbouring tile groups land on
+    // different XCDs, which balances the heavy (many-light) screen regions over the chip.  Giving
+    // each XCD one contiguous run of tiles measured 15 % slower on the headline frame (imbalance),
+    // and nothing is lost: a workgroup already reads whole 256-byte row segments by itself.
+    const uint32_t bpr = (p.tiles_x + wpb - 1) / wpb, blk = blockIdx.x;
+    const uint32_t tyi = blk / bpr, txi = (blk - tyi * bpr) * wpb + wv;
+    if (txi >= p.tiles_x) return;                       // whole wave; nothing below synchronises across waves
 
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t x = txi * TILE + (tid & 15u), y = tyi * TILE + (tid >> 4);
-    const bool inb = x < p.width && y < p.height;
-    uint32_t u1 = 0, u2 = 0, u3 = 0;
-    float depth = 1.0f;
-    if (inb) {
-        size_t i = (size_t)y * p.pitch + x;
-        u1 = p.normal[i]; u2 = p.albedo[i]; u3 = p.rm[i]; depth = p.depth[i];
-    }
-    Px q;
-    setup_pixel(q, p, x, y, u1, u2, u3, depth);
-    const bool lit = inb && (u2 >> 24) != 0;    // occlusion 0 => every point-light term is exactly 0
-
-    // ---- 1. tile AABB (+ shadow rectangle) ----
+    // ---- 1/2. AABB of lit pixels + shadow texel rectangle.  Needs only depth and occlusion of the
+    //          256 pixels; nothing of it stays in registers (the passes re-fetch their texels, L2 hits).
+    const uint32_t x = txi * TILE + (lane & 15u), y0 = tyi * TILE + (lane >> 4);
+    const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
+    const bool xin = x < p.width;
+    const v4f *cull = (const v4f *)p.point_cull;
     const float INF = __builtin_inff();
-    f3 lo = { lit ? q.P.x : INF, lit ? q.P.y : INF, lit ? q.P.z : INF };
-    f3 hi = { lit ? q.P.x : -INF, lit ? q.P.y : -INF, lit ? q.P.z : -INF };
-    const bool want_box = p.n_point > 0;
-    if (want_box) {
+    f3 lo = { INF, INF, INF }, hi = { -INF, -INF, -INF };
+    const bool do_shadow = p.has_shadow && p.n_dir > 0;
+    const bool stage = do_shadow && p.shadow_lds;
+    int x0 = 0x7FFFFFFF, x1 = -0x7FFFFFFF, yy0 = 0x7FFFFFFF, yy1 = -0x7FFFFFFF;
+    if (p.n_point > 0 || stage) {
+        uint32_t w2[4];
+        float dz[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {                   // clamped, not branched: straight-line loads
+            const size_t i = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
+            w2[j] = p.albedo[i]; dz[j] = p.depth[i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const f3 P = pixel_position(p, x, y0 + 4 * j, dz[j]);
+            const bool lit = xin && (y0 + 4 * j) <= ylast && (w2[j] >> 24) != 0;   // occlusion 0 => every point-light term is exactly 0
+            if (lit) {
+                lo.x = fminf(lo.x, P.x); lo.y = fminf(lo.y, P.y); lo.z = fminf(lo.z, P.z);
+                hi.x = fmaxf(hi.x, P.x); hi.y = fmaxf(hi.y, P.y); hi.z = fmaxf(hi.z, P.z);
+                if (stage) {
+                    const ShadowTap t = shadow_tap(P, p);
+                    if (t.inside) { x0 = min(x0, t.tx); x1 = max(x1, t.tx); yy0 = min(yy0, t.ty); yy1 = max(yy1, t.ty); }
+                }
+            }
+        }
+    }
+    bool any_lit = false;
+    if (p.n_point > 0) {
         lo.x = wave_min(lo.x); lo.y = wave_min(lo.y); lo.z = wave_min(lo.z);
         hi.x = wave_max(hi.x); hi.y = wave_max(hi.y); hi.z = wave_max(hi.z);
-        if (lane == 0) {
-            s_box[wv][0] = lo.x; s_box[wv][1] = lo.y; s_box[wv][2] = lo.z;
-            s_box[wv][3] = hi.x; s_box[wv][4] = hi.y; s_box[wv][5] = hi.z;
-        }
+        any_lit = lo.x <= hi.x;
     }
-    const bool do_shadow = p.has_shadow && p.n_dir > 0;
-    ShadowTap st = { 0, 0, 0.0f, false };
-    if (do_shadow) {
-        st = shadow_tap(q, p);
-        if (p.shadow_lds) {
-            bool use = st.inside && lit;
-            int x0 = wave_mini(use ? st.tx : 0x7FFFFFFF), x1 = wave_maxi(use ? st.tx : -0x7FFFFFFF);
-            int y0 = wave_mini(use ? st.ty : 0x7FFFFFFF), y1 = wave_maxi(use ? st.ty : -0x7FFFFFFF);
-            if (lane == 0) { s_rect[wv][0] = x0; s_rect[wv][1] = x1; s_rect[wv][2] = y0; s_rect[wv][3] = y1; }
-        }
-    }
-    __syncthreads();
-    if (want_box) {
-        lo.x = fminf(fminf(s_box[0][0], s_box[1][0]), fminf(s_box[2][0], s_box[3][0]));
-        lo.y = fminf(fminf(s_box[0][1], s_box[1][1]), fminf(s_box[2][1], s_box[3][1]));
-        lo.z = fminf(fminf(s_box[0][2], s_box[1][2]), fminf(s_box[2][2], s_box[3][2]));
-        hi.x = fmaxf(fmaxf(s_box[0][3], s_box[1][3]), fmaxf(s_box[2][3], s_box[3][3]));
-        hi.y = fmaxf(fmaxf(s_box[0][4], s_box[1][4]), fmaxf(s_box[2][4], s_box[3][4]));
-        hi.z = fmaxf(fmaxf(s_box[0][5], s_box[1][5]), fmaxf(s_box[2][5], s_box[3][5]));
-    }
-    const bool any_lit = want_box && lo.x <= hi.x;
-
-    // ---- 2. shadow factor, taps from LDS when the tile's texel rectangle fits ----
-    float shadow = 1.0f;
-    if (do_shadow) {
-        bool staged = false;
-        int rx0 = 0, ry0 = 0, rw = 0;
-        if (p.shadow_lds) {
-            int x0 = min(min(s_rect[0][0], s_rect[1][0]), min(s_rect[2][0], s_rect[3][0]));
-            int x1 = max(max(s_rect[0][1], s_rect[1][1]), max(s_rect[2][1], s_rect[3][1]));
-            int y0 = min(min(s_rect[0][2], s_rect[1][2]), min(s_rect[2][2], s_rect[3][2]));
-            int y1 = max(max(s_rect[0][3], s_rect[1][3]), max(s_rect[2][3], s_rect[3][3]));
-            if (x0 <= x1) {
-                rw = x1 - x0 + 3;
-                int rh = y1 - y0 + 3;
-                rx0 = x0 - 1; ry0 = y0 - 1;
-                if ((long long)rw * rh <= SH_CAP) {
-                    staged = true;
-                    const int S = (int)p.shadow_size;
-                    for (int yy = (int)(tid >> 4); yy < rh; yy += 16) {
-                        int sy = min(max(ry0 + yy, 0), S - 1);      // clamp-to-edge baked into the staged copy
-                        for (int xx = (int)(tid & 15u); xx < rw; xx += 16) {
-                            int sx = min(max(rx0 + xx, 0), S - 1);
-                            s_shadow[yy * rw + xx] = p.shadow_map[(size_t)sy * S + sx];
-                        }
+    bool staged = false;
+    int rx0 = 0, ry0 = 0, rw = 0;
+    if (stage) {
+        x0 = wave_mini(x0); x1 = wave_maxi(x1); yy0 = wave_mini(yy0); yy1 = wave_maxi(yy1);
+        if (x0 <= x1) {
+            rw = x1 - x0 + 3;
+            const int rh = yy1 - yy0 + 3;
+            rx0 = x0 - 1; ry0 = yy0 - 1;
+            if ((long long)rw * rh <= SH_CAP) {
+                staged = true;
+                const int S = (int)p.shadow_size;
+                for (int yy = (int)(lane >> 4); yy < rh; yy += 4) {
+                    const int sy = min(max(ry0 + yy, 0), S - 1);      // clamp-to-edge baked into the staged copy
+                    for (int xx = (int)(lane & 15u); xx < rw; xx += 16) {
+                        const int sx = min(max(rx0 + xx, 0), S - 1);
+                        s_shadow[yy * rw + xx] = p.shadow_map[(size_t)sy * S + sx];
                     }
                 }
+                __builtin_amdgcn_wave_barrier();   // LDS ops of one wave execute in order; keep the compiler from reordering
             }
-            __syncthreads();   // uniform: every thread of the block takes the p.shadow_lds branch
-        }
-        if (staged) {
-            if (st.inside && lit) {
-                int cnt = 0, bx = st.tx - rx0, by = st.ty - ry0;
-#pragma unroll
-                for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                    for (int dx = -1; dx <= 1; dx++) cnt += (st.zc <= s_shadow[(by + dy) * rw + bx + dx]) ? 1 : 0;
-                shadow = pcf_result(cnt);
-            }
-        } else if (lit) {
-            shadow = pcf_direct(st, p);
         }
     }
 
-    // ---- directional lights first, in index order (fs_deferred_lighting.glsl:62-64) ----
-    f3 res = { 0.0f, 0.0f, 0.0f };
-    for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, p, l, shadow, do_shadow && l == 0, res);
-
-    // ---- 3/4. point lights: cull a chunk into LDS, shade it, next chunk ----
     uint32_t total = 0;
-    if (any_lit) {
-        for (uint32_t base = 0; base < p.n_point; base += CHUNK) {
-            uint32_t cnt = 0;
-            const uint32_t wbase = base + wv * SUB;
-            for (uint32_t j = 0; j < SUB; j += 64) {
-                uint32_t li = wbase + j + lane;
-                if (wbase + j >= p.n_point) break;      // wave-uniform
-                bool pass = false;
-                if (li < p.n_point) {
-#if MIL_STRICT
-                    v4f a = ((const v4f *)p.point_raw)[2 * li];
-#else
-                    v4f a = ((const v4f *)p.point_prep)[2 * li];
-#endif
-                    pass = box_d2(a, lo, hi) < point_r2(a);
-                }
-                unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+#pragma unroll 1
+    for (uint32_t ch = 0; ch < n_chunks; ch++) {
+        // ---- 3. cull this chunk of lights into the wave's LDS list (ascending order) ----
+        const uint32_t base = ch * CHUNK, end = min(base + (uint32_t)CHUNK, p.n_point);
+        uint32_t cnt = 0;
+        if (any_lit) {
+            for (uint32_t b0 = base; b0 < end; b0 += 64) {
+                const uint32_t li = b0 + lane;
+                v4f c = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if (li < end) c = cull[li];
+                const bool pass = li < end && box_d2(c, lo, hi) < c.w * c.w;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                 if (pass) {
-                    uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    s_list[wv][pos] = (uint16_t)(li - base);
+                    const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    s_list[pos] = (uint16_t)(li - base);
                 }
                 cnt += (uint32_t)__builtin_popcountll(m);
             }
-            if (lane == 0) s_cnt[wv] = cnt;
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
+        }
+        total += cnt;
+
+        // ---- 5. four passes of 64 pixels; pass j+1's texels are requested before pass j is shaded ----
+        struct Texel { uint32_t u1, u2, u3; float depth; };
+        auto fetch = [&](uint32_t j) {
+            const size_t i = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
+            return Texel{ p.normal[i], p.albedo[i], p.rm[i], p.depth[i] };
+        };
+        Texel t = fetch(0);
 #pragma unroll 1
-            for (uint32_t w = 0; w < 4; w++) {
-                const uint32_t n = s_cnt[w];
-                total += n;
+        for (uint32_t j = 0; j < 4; j++) {
+            const Texel tn = fetch(min(j + 1, 3u));
+            const uint32_t y = y0 + 4 * j;
+            const uint32_t w2 = t.u2;
+            const bool inbj = xin && y <= ylast, litj = inbj && (w2 >> 24) != 0;
+            Px q;
+            setup_pixel(q, p, pixel_position(p, x, y, t.depth), t.u1, w2, t.u3);
+            f3 r = { 0.0f, 0.0f, 0.0f };
+            if (ch == 0) {
+                float shadow = 1.0f;
+                if (do_shadow && litj) {
+                    const ShadowTap st = shadow_tap(q.P, p);
+                    if (staged) {
+                        if (st.inside) {
+                            int c9 = 0;
+                            const int bx = st.tx - rx0, by = st.ty - ry0;
+#pragma unroll
+                            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                                for (int dx = -1; dx <= 1; dx++) c9 += (st.zc <= s_shadow[(by + dy) * rw + bx + dx]) ? 1 : 0;
+                            shadow = pcf_result(c9);
+                        }
+                    } else {
+                        shadow = pcf_direct(st, p);
+                    }
+                }
+                for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
+            } else {
+                r = f3{ s_res[j * 64 + lane], s_res[256 + j * 64 + lane], s_res[512 + j * 64 + lane] };
+            }
+            if (cnt) {
+                // software pipeline: record k+1 is requested (scalar cache) while record k is evaluated
+                uint32_t li = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[0]);
+                v4f a = point_rec_a(p, li), bb = point_rec_b(p, li);
 #pragma unroll 1
-                for (uint32_t k = 0; k < n; k++) {
-                    uint32_t li = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[w][k]);
-                    add_point(q, p, li, res);
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const uint32_t kn = min(k + 1, cnt - 1);
+                    const uint32_t ln = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[kn]);
+                    const v4f an = point_rec_a(p, ln), bn = point_rec_b(p, ln);
+                    add_point(q, a, bb, r);
+                    a = an; bb = bn;
                 }
             }
-            __syncthreads();
+            if (ch + 1 == n_chunks) {
+                if (p.has_ambient) add_ambient(q, p, w2, r);
+                if (inbj) store_pixel<FMT>(p, x, y, r);
+            } else {
+                s_res[j * 64 + lane] = r.x; s_res[256 + j * 64 + lane] = r.y; s_res[512 + j * 64 + lane] = r.z;
+            }
+            t = tn;
         }
+        __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next chunk only after these reads were issued
     }
-    if (p.tile_counts && tid == 0) p.tile_counts[tile] = total;
-    if (p.has_ambient) add_ambient(q, p, res);
-    if (inb) store_pixel<FMT>(p, x, y, res);
+    if (p.tile_counts && lane == 0) p.tile_counts[tyi * p.tiles_x + txi] = total;
 }
 
 // ---------------------------------------------------------------------------------
@@ -624,7 +721,7 @@ __global__ __launch_bounds__(256) void k_count_pairs(const ShadeParams p, unsign
     if (x < p.width && y < p.height) {
         size_t i = (size_t)y * p.pitch + x;
         Px q;
-        setup_pixel(q, p, x, y, p.normal[i], p.albedo[i], p.rm[i], p.depth[i]);
+        setup_pixel(q, p, pixel_position(p, x, y, p.depth[i]), p.normal[i], p.albedo[i], p.rm[i]);
         if (q.occ > 0.0f)
             for (uint32_t l = 0; l < p.n_point; l++) {
                 v4f a = ldu(p.point_prep, 2 * l);
@@ -643,22 +740,33 @@ __global__ __launch_bounds__(256) void k_count_pairs(const ShadeParams p, unsign
 // ---------------------------------------------------------------------------------
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s)
 {
-    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    const bool four = p.rows_per_block == 4;
+    dim3 block(64, 4), grid((p.width + 63) / 64, four ? (p.height + 15) / 16 : (p.height + 3) / 4);
+    const bool ext = p.has_shadow || p.n_point || p.has_ambient;
+#define MIL_LAUNCH_STREAM(F)                                                              \
+    if (four) { if (ext) hipLaunchKernelGGL((k_stream<F, 4, true>), grid, block, 0, s, p);  \
+                else hipLaunchKernelGGL((k_stream<F, 4, false>), grid, block, 0, s, p); }   \
+    else { if (ext) hipLaunchKernelGGL((k_stream<F, 1, true>), grid, block, 0, s, p);       \
+           else hipLaunchKernelGGL((k_stream<F, 1, false>), grid, block, 0, s, p); }
     switch (fmt) {
-    case FMT_HDR: hipLaunchKernelGGL(k_stream<FMT_HDR>, grid, block, 0, s, p); break;
-    case FMT_LDR: hipLaunchKernelGGL(k_stream<FMT_LDR>, grid, block, 0, s, p); break;
-    case FMT_SRGB8: hipLaunchKernelGGL(k_stream<FMT_SRGB8>, grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL(k_stream<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
+    case FMT_HDR: MIL_LAUNCH_STREAM(FMT_HDR); break;
+    case FMT_LDR: MIL_LAUNCH_STREAM(FMT_LDR); break;
+    case FMT_SRGB8: MIL_LAUNCH_STREAM(FMT_SRGB8); break;
+    default: MIL_LAUNCH_STREAM(FMT_SRGB8_VIA_LDR); break;
     }
+#undef MIL_LAUNCH_STREAM
 }
 void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s)
 {
-    dim3 block(256), grid(p.tiles_x * p.tiles_y);
+    const uint32_t wpb = (p.tune & 2u) ? 1 : ((p.tune & 4u) ? 2 : 4);
+    dim3 block(64 * wpb), grid(((p.tiles_x + wpb - 1) / wpb) * p.tiles_y);
+    const size_t lds = wpb * (CHUNK * sizeof(uint16_t) + (p.n_point > (uint32_t)CHUNK ? 768 * sizeof(float) : 0) +
+                              ((p.has_shadow && p.shadow_lds && p.n_dir) ? SH_CAP * sizeof(float) : 0));
     switch (fmt) {
-    case FMT_HDR: hipLaunchKernelGGL(k_tiled<FMT_HDR>, grid, block, 0, s, p); break;
-    case FMT_LDR: hipLaunchKernelGGL(k_tiled<FMT_LDR>, grid, block, 0, s, p); break;
-    case FMT_SRGB8: hipLaunchKernelGGL(k_tiled<FMT_SRGB8>, grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL(k_tiled<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
+    case FMT_HDR: hipLaunchKernelGGL(k_tiled<FMT_HDR>, grid, block, lds, s, p); break;
+    case FMT_LDR: hipLaunchKernelGGL(k_tiled<FMT_LDR>, grid, block, lds, s, p); break;
+    case FMT_SRGB8: hipLaunchKernelGGL(k_tiled<FMT_SRGB8>, grid, block, lds, s, p); break;
+    default: hipLaunchKernelGGL(k_tiled<FMT_SRGB8_VIA_LDR>, grid, block, lds, s, p); break;
     }
 }
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)

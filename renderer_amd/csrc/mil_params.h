@@ -8,6 +8,8 @@
 
 namespace mil {
 
+#define MIL_DIR_INLINE 4u
+
 struct ShadeParams {
     // G-buffer planes (device), see mil_gbuffer
     const uint32_t *normal, *albedo, *rm;
@@ -19,10 +21,14 @@ struct ShadeParams {
     float sx, ox, sy, oy;   // fast path: clip.xy = (x, y_global) * s + o  ==  ((x+0.5)/res)*2-1
     // staged light arrays (device): each record = 2 float4
     uint32_t n_dir, n_point;
+    float dir_inline[MIL_DIR_INLINE][8]; // first records in this launch's mode layout (raw if strict, else prepared)
     const float4 *dir_raw;    // {direction.xyz, intensity} {color.xyz, pad}               (strict)
     const float4 *dir_prep;   // {direction.xyz, 0} {color.xyz * intensity, 0}             (fast)
     const float4 *point_raw;  // {position.xyz, radius} {color.xyz, intensity}             (strict)
-    const float4 *point_prep; // {position.xyz, radius^2} {color.xyz * intensity, 1/r^2}   (fast + culling)
+    const float4 *point_prep; // {position.xyz, radius^2} {color.xyz * intensity, 1/r^2}   (fast)
+    const float4 *point_cull; // {position.xyz, radius}, 16 bytes per light                 (tile culling, both modes)
+    uint32_t rows_per_block;  // K1: pixels per lane (1 or 4; tuning)
+    uint32_t tune;            // experiment bits (env MIL_TUNE): 1 = no XCD remap in K2
     float ambient[3];
     uint32_t has_ambient;
     // shadow extension

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libmil.so')
 
 OUT_HDR, OUT_LDR, OUT_SRGB8, OUT_SRGB8_VIA_LDR = 0, 1, 2, 3
-FLAG_STRICT, FLAG_NO_CULL, FLAG_SHADOW_DIRECT = 1, 2, 4
+FLAG_STRICT, FLAG_NO_CULL, FLAG_SHADOW_LDS = 1, 2, 4
 TILE = 16
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',

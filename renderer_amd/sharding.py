@@ -1,0 +1,105 @@
+"""Multi-GPU sharding of the lighting pass: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+The reference is single-GPU (/root/reference/renderer/src/render/vulkan.rs:106-108 picks
+one PhysicalDevice); the pass itself is embarrassingly parallel per pixel
+(shaders/fs_deferred_lighting.glsl:40-67 reads only its own texel + uniforms), so there is
+no exchange during shading and exactly one collective at the end: gather to rank 0.
+
+  strips  one frame cut into horizontal strips on 16-row boundaries (tiles never straddle
+          ranks); PositionFromDepth needs the global row, passed as y_offset.
+  frames  a batch of frames dealt to ranks; each rank shades whole frames.
+
+RCCL has no gather primitive; the gather is grouped point-to-point (every sender uses its
+own xGMI link to GPU 0), expressed as dist.batch_isend_irecv, receiving straight into the
+destination image on rank 0 (no staging copy).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ubo
+
+TILE = 16
+
+
+def strip_bounds(height, n, align=TILE):
+    """n contiguous strips, every cut a multiple of `align` rows: 2160 -> 7x272 + 256,
+    4320 -> 7x544 + 512.  Trailing ranks may get an empty strip."""
+    rows = int(math.ceil(height / n / align) * align)
+    cuts = [min(height, i * rows) for i in range(n + 1)]
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def frame_assignment(n_frames, world, rank):
+    """Blocked deal of frame indices: rank r gets a contiguous run."""
+    per = int(math.ceil(n_frames / world))
+    return list(range(min(n_frames, rank * per), min(n_frames, (rank + 1) * per)))
+
+
+def orbit_camera(frame_idx, n_frames, width, height):
+    """Animated camera of the frame-parallel config: yaw += 2*pi/n_frames per frame around the
+    sphere wall's centre, same projection as main.rs:70-78."""
+    a = 2.0 * math.pi * frame_idx / n_frames
+    centre = np.array([0.0, 7.5, 4.5])
+    eye = centre + 9.0 * np.array([math.cos(a), 0.0, math.sin(a)])
+    fwd = centre - eye
+    return ubo.PerspectiveCamera(position=eye, forward=fwd / np.linalg.norm(fwd), up=(0.0, -1.0, 0.0),
+                                 fov_deg=90.0, aspect_ratio=width / height, near=0.05, far=100.0)
+
+
+def gather_strips(local, bounds, full=None, dst=0, group=None, async_op=False):
+    """Gather row strips to rank `dst`.  local: this rank's (rows, width, ...) tensor;
+    full (rank dst only): (height, width, ...) destination.  Returns the list of pending
+    requests when async_op, else waits."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ops = []
+    if rank == dst:
+        y0, y1 = bounds[dst]
+        if y1 > y0:
+            full[y0:y1].copy_(local)
+        for r in range(world):
+            y0, y1 = bounds[r]
+            if r != dst and y1 > y0:
+                ops.append(dist.P2POp(dist.irecv, full[y0:y1], r, group))
+    else:
+        y0, y1 = bounds[rank]
+        if y1 > y0:
+            ops.append(dist.P2POp(dist.isend, local, dst, group))
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if not async_op:
+        for q in reqs:
+            q.wait()
+        return []
+    return reqs
+
+
+def gather_frames(local, slots=None, dst=0, group=None, async_op=False):
+    """Gather one finished frame per rank to rank `dst`.  slots (rank dst only): list of
+    world tensors shaped like `local`; slots[dst] is filled by a device copy."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ops = []
+    if rank == dst:
+        slots[dst].copy_(local)
+        ops = [dist.P2POp(dist.irecv, slots[r], r, group) for r in range(world) if r != dst]
+    else:
+        ops = [dist.P2POp(dist.isend, local, dst, group)]
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+    if not async_op:
+        for q in reqs:
+            q.wait()
+        return []
+    return reqs
+
+
+def render_strips(shade_fn, make_strip, height, full=None, dst=0, group=None):
+    """One frame, strip-sharded.  make_strip(y0, y1) -> this rank's G-buffer strip;
+    shade_fn(strip) -> (rows, width, ...) tensor.  Returns `full` on rank dst."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    bounds = strip_bounds(height, world)
+    y0, y1 = bounds[rank]
+    local = shade_fn(make_strip(y0, y1)) if y1 > y0 else None
+    gather_strips(local, bounds, full, dst, group)
+    return full if rank == dst else None

@@ -216,7 +216,7 @@ def test_extensions_strict_bit_exact(lp, coracle, kind, w, h, n_point):
     gb, frame, dl, pl, sh = make_scene(kind, w, h, n_point=n_point, shadow=256)
     ref = coracle.shade(*planes_np(gb), frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh))
     S = lighting.FLAG_STRICT
-    for fl in (S, S | lighting.FLAG_NO_CULL, S | lighting.FLAG_SHADOW_DIRECT, S | lighting.FLAG_NO_CULL | lighting.FLAG_SHADOW_DIRECT):
+    for fl in (S, S | lighting.FLAG_NO_CULL, S | lighting.FLAG_SHADOW_LDS, S | lighting.FLAG_NO_CULL | lighting.FLAG_SHADOW_LDS):
         assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=fl).cpu().numpy(), ref, f'flags {fl}')
 
 
@@ -293,6 +293,20 @@ def test_strips_equal_monolithic(lp, strict):
             assert torch.equal(gen['depth'], gb['depth'][y0:y1]) and torch.equal(gen['normal'], gb['normal'][y0:y1])
 
 
+def test_light_staging_ring_and_cache(lp, coracle):
+    """Light arrays are staged through a 4-slot ring and re-used when unchanged: alternate more
+    distinct light sets than slots, with repeats, and check every frame against the oracle."""
+    gb, frame, dl, _, _ = make_scene('sweep', 96, 54)
+    sets = [synth.point_light_field(40 + 7 * i, 100 + i) for i in range(6)]
+    order = [0, 0, 1, 2, 3, 4, 5, 0, 5, 5, 1]
+    outs = [lp.light_ex(gb, frame, dl, sets[i], flags=lighting.FLAG_STRICT) for i in order]   # enqueue all, then check
+    for i, o in zip(order, outs):
+        assert_bits_equal(o.cpu().numpy(), coracle.shade(*planes_np(gb), frame, dl, point_lights=sets[i]), f'set {i}')
+    many = ubo.directional_lights([((1, 2 + i, 0.5 * i), 0.1, (1, 1, 1)) for i in range(9)])   # > 4 inline records
+    a = lp.light_directional(gb, frame, many, strict=True).cpu().numpy()
+    assert_bits_equal(a, coracle.shade(*planes_np(gb), frame, many), '9 directional lights')
+
+
 def test_count_pairs(lp, coracle):
     gb, frame, dl, pl, _ = make_scene('sweep', 160, 90, n_point=100)
     _, pairs = coracle.shade(*planes_np(gb), frame, dl[:0], point_lights=pl, return_pairs=True)
@@ -305,7 +319,7 @@ def test_4k_properties(lp):
     w, h = 3840, 2160
     gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=256, shadow=2048)
     a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
-    b = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL | lighting.FLAG_SHADOW_DIRECT)
+    b = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL | lighting.FLAG_SHADOW_LDS)
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))             # culled + LDS-staged == brute force + direct
     assert torch.isfinite(a).all() and torch.all(a[..., 3] == 1)
     # strips at 16-row-aligned cuts (2160 = 7*272 + 256)

@@ -1,0 +1,42 @@
+"""Condenses a tools/profile_round.sh output directory into small text/JSON summaries."""
+import collections, csv, glob, json, os, sys
+O, R = sys.argv[1], sys.argv[2]
+out = []
+# --- kernel stats (rocprofv3 --kernel-trace --stats)
+for f in glob.glob(f'{O}/stats/**/*kernel_stats.csv', recursive=True):
+    out.append(f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu   ({os.path.basename(f)})')
+    rows = list(csv.DictReader(open(f)))
+    out.append(f'{"kernel":70s} {"calls":>6s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s} {"pct":>6s}')
+    for r in rows:
+        if 'mil::' not in r['Name'] and float(r['Percentage']) < 2.0: continue
+        out.append(f'{r["Name"][:70]:70s} {r["Calls"]:>6s} {float(r["AverageNs"])/1e3:10.2f} {float(r["MinNs"])/1e3:10.2f} {float(r["MaxNs"])/1e3:10.2f} {float(r["Percentage"]):6.2f}')
+# --- PMC
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f'{O}/pmc_*/**/*counter_collection.csv', recursive=True):
+    case = f.split('/pmc_')[1].split('_')[0]
+    for row in csv.DictReader(open(f)):
+        k = row['Kernel_Name'].split('(')[0]
+        if 'mil::' not in k: continue
+        agg[(case, k)][row['Counter_Name']].append(float(row['Counter_Value']))
+traffic = {}
+out.append('')
+out.append('# rocprofv3 --pmc passes (tools/run_case.py <case> 9), mean over dispatches 4..9')
+for (case, k), cs in sorted(agg.items()):
+    out.append(f'[{case}] {k}')
+    m = {}
+    for c, v in sorted(cs.items()):
+        v = v[3:] if len(v) > 3 else v
+        m[c] = sum(v) / len(v)
+        out.append(f'   {c:24s} {m[c]:18.1f}')
+    if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KiB) reads exactly half of a coalesced stream's bytes on
+        # gfx950 -> x2; WRITE_SIZE (KiB) is exact for 16-B-per-lane streaming stores.
+        rd, wr = 2 * m['FETCH_SIZE'] * 1024, m['WRITE_SIZE'] * 1024
+        out.append(f'   -> HBM bytes/launch: read {rd/1e6:.1f} MB (2 x FETCH_SIZE), write {wr/1e6:.1f} MB, total {(rd+wr)/1e6:.1f} MB')
+        kn = 'k_tiled' if 'k_tiled' in k else ('k_stream' if 'k_stream' in k else k)
+        wl = {'headline': 'headline', 'k1': 'k1_1light'}[case]
+        traffic[f'{wl}:{kn}'] = dict(hbm_bytes_per_launch=int(rd + wr), fetch_size_kib=m['FETCH_SIZE'], write_size_kib=m['WRITE_SIZE'],
+                                     note='read = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM), write = WRITE_SIZE KiB')
+open(f'{O}/summary_{R}.txt', 'w').write('\n'.join(out) + '\n')
+json.dump(traffic, open(f'{O}/pmc_traffic.json', 'w'), indent=1)
+print('\n'.join(out))

@@ -1,0 +1,27 @@
+"""Runs ONE kernel configuration N times (for rocprofv3 passes).  usage: run_case.py <case> [iters]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from renderer_amd import lighting, synth, ubo
+case = sys.argv[1]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+W, H = 3840, 2160
+dev = 'cuda:0'
+lp = lighting.LightingPass(0, 4096)
+cam = synth.sweep_camera(W, H)
+gbs = [synth.scene_sweep(W, H, cam, device=dev)]
+for _ in range(2): gbs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in gbs[0].items()})
+frame = cam.frame_matrix_data(); dl = ubo.default_directional_lights(); pl = synth.point_light_field(int(os.environ.get('NPT', '256')), 0x5EED0003)
+sh = synth.shadow_setup(dl[0, :3], 2048, device=dev); amb = (0.03,) * 3
+hdrs = [torch.empty((H, W, 4), device=dev) for _ in range(3)]
+outs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(3)]
+torch.cuda.synchronize()
+for i in range(iters):
+    k = i % 3
+    if case == 'k1': lp.light_directional(gbs[k], frame, dl[:1], out=hdrs[k])
+    elif case == 'k1_2': lp.light_directional(gbs[k], frame, dl, out=hdrs[k])
+    elif case == 'headline': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, out=hdrs[k])
+    elif case == 'headline_lds': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, flags=4, out=hdrs[k])
+    elif case == 'points': lp.light_ex(gbs[k], frame, dl[:0], pl, None, None, out=hdrs[k])
+    elif case == 'tonemap': lp.tonemap(hdrs[k], 2, out=outs[k])
+    else: raise SystemExit('unknown case')
+torch.cuda.synchronize()
