@@ -182,6 +182,28 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
     p.res_x = push->resolution[0]; p.res_y = push->resolution[1];
     p.sx = 2.0f / p.res_x; p.ox = 1.0f / p.res_x - 1.0f;
     p.sy = 2.0f / p.res_y; p.oy = 1.0f / p.res_y - 1.0f;
+    // fast path: world.xyz - cam = ((inv_view - [0|cam]) * (v / v.w)).xyz = (inv_view * v).xyz / v.w with v = inv_proj * clip and
+    // clip = (x*sx+ox, y*sy+oy, depth, 1): fold everything acting on (x, y_global, depth, 1) into one 4x4, in double
+    {
+        const float *ip = f->inv_projection, *iv = f->inv_view;   // column-major: m[c*4 + r]
+        double C[4][4] = { { 2.0 / p.res_x, 0, 0, 1.0 / p.res_x - 1.0 }, { 0, 2.0 / p.res_y, 0, 1.0 / p.res_y - 1.0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+        double PC[4][4], A[4][4];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) {
+                double a = 0;
+                for (int k = 0; k < 4; k++) a += (double)ip[k * 4 + r] * C[k][c];
+                PC[r][c] = a;
+            }
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++) {
+                double a = 0;
+                for (int k = 0; k < 4; k++) a += ((double)iv[k * 4 + r] - (k == 3 ? (double)f->camera_position[r] : 0.0)) * PC[k][c];
+                A[r][c] = a;   // rows 0-2 yield P - cameraPosition
+            }
+        for (int c = 0; c < 4; c++) A[3][c] = PC[3][c];
+        for (int r = 0; r < 4; r++)
+            for (int c = 0; c < 4; c++) p.pos_m[r * 4 + c] = (float)A[r][c];
+    }
     p.tiles_x = (gb->width + MIL_TILE - 1) / MIL_TILE;
     p.tiles_y = (gb->height + MIL_TILE - 1) / MIL_TILE;
 }

@@ -73,8 +73,9 @@ struct Px {
     float alpha, metallic;
 #else
     float alpha, a2, am1, NdotV, sV;   // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
-    f3 F0, dF;                         // dF = f90 - F0
-    f3 dif, tint;                      // albedo/PI*(1-m)*occ ; ((1-m) + albedo*m)*occ
+    float NdotVraw;                    // dot(N, V) before the clamp (point lights: N.H = (N.L + N.V) / |L + V|)
+    f3 G0, G1;                         // tint * F0, tint * (f90 - F0), tint = ((1-m) + albedo*m)*occ
+    f3 dif;                            // albedo/PI*(1-m)*occ
 #endif
 };
 
@@ -92,18 +93,20 @@ DEV float mrow(const float *m, int r, float x, float y, float z, float w)
 }
 
 // PositionFromDepth, fs_deferred_lighting.glsl:30-38 (y is the strip-local row)
-DEV f3 pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+struct Pos { f3 P; };
+DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
 {
     float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
     float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
     float vx = mrow(p.inv_proj, 0, px, py, depth, 1.0f), vy = mrow(p.inv_proj, 1, px, py, depth, 1.0f);
     float vz = mrow(p.inv_proj, 2, px, py, depth, 1.0f), vw = mrow(p.inv_proj, 3, px, py, depth, 1.0f);
     vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
-    return f3{ mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
+    return Pos{ f3{ mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) } };
 }
 
-DEV void setup_pixel(Px &q, const ShadeParams &p, f3 P, uint32_t u1, uint32_t u2, uint32_t u3)
+DEV void setup_pixel(Px &q, const ShadeParams &p, Pos pos, uint32_t u1, uint32_t u2, uint32_t u3)
 {
+    const f3 P = pos.P;
     f3 b1 = { (float)(u1 & 0x3FF) / 1023.0f, (float)((u1 >> 10) & 0x3FF) / 1023.0f, (float)((u1 >> 20) & 0x3FF) / 1023.0f };
     q.albedo = f3{ (float)(u2 & 0xFF) / 255.0f, (float)((u2 >> 8) & 0xFF) / 255.0f, (float)((u2 >> 16) & 0xFF) / 255.0f };
     q.occ = (float)(u2 >> 24) / 255.0f;
@@ -165,11 +168,17 @@ DEV float point_d2(const Px &q, v4f a, f3 &Lv)
 DEV float point_r2(v4f a) { return a.w * a.w; }
 DEV v4f point_rec_a(const ShadeParams &p, uint32_t l) { return ldu(p.point_raw, 2 * l); }
 DEV v4f point_rec_b(const ShadeParams &p, uint32_t l) { return ldu(p.point_raw, 2 * l + 1); }
-DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
+DEV v4f point_rec_a_v(const ShadeParams &p, uint32_t l) { return ((const v4f *)p.point_raw)[2 * l]; }   // per-lane (vector) fetch
+DEV v4f point_rec_b_v(const ShadeParams &p, uint32_t l) { return ((const v4f *)p.point_raw)[2 * l + 1]; }
+DEV bool point_test(const Px &q, v4f a, f3 &Lv, float &d2)
 {
-    f3 Lv;
-    float d2 = point_d2(q, a, Lv), r2 = point_r2(a);
-    if (d2 < r2 && q.occ > 0.0f) {
+    d2 = point_d2(q, a, Lv);
+    return d2 < point_r2(a) && q.occ > 0.0f;
+}
+DEV void point_eval(const Px &q, v4f a, v4f b, f3 Lv, float d2, bool on, f3 &res)
+{
+    if (on) {
+        float r2 = point_r2(a);
         float inv = 1.0f / sqrtf(fmaxf(d2, 1e-12f));
         f3 L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
         float qq = d2 / r2, w = clampf(1.0f - qq * qq, 0.0f, 1.0f);
@@ -179,6 +188,13 @@ DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
         res.y += ((c.y * b.w) * att) * q.occ;
         res.z += ((c.z * b.w) * att) * q.occ;
     }
+}
+DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
+{
+    f3 Lv;
+    float d2;
+    const bool on = point_test(q, a, Lv, d2);
+    point_eval(q, a, b, Lv, d2, on, res);
 }
 DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t, f3 &res)
 {
@@ -214,17 +230,27 @@ DEV float mrow1(const float *m, int r, float x, float y, float z)   // w == 1
     return __builtin_fmaf(m[0 + r], x, __builtin_fmaf(m[4 + r], y, __builtin_fmaf(m[8 + r], z, m[12 + r])));
 }
 
-DEV f3 pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+// PositionFromDepth with the two matrix products and the pixel -> clip map folded on the host
+// (mil_api.cpp fill_common, in double).  The folded matrix carries inv_view's translation MINUS the
+// camera position, so what comes out is D = P - cameraPosition without the cancellation the literal
+// form has near the camera (V = normalize(-D)); P = D + cameraPosition.
+//   D = (A . (x, y_global, depth, 1)).xyz / (A . (...)).w
+struct Pos { f3 P, D; };
+DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
 {
-    float px = __builtin_fmaf((float)x, p.sx, p.ox), py = __builtin_fmaf((float)(y + p.y_offset), p.sy, p.oy);
-    float vx = mrow1(p.inv_proj, 0, px, py, depth), vy = mrow1(p.inv_proj, 1, px, py, depth);
-    float vz = mrow1(p.inv_proj, 2, px, py, depth), vw = mrow1(p.inv_proj, 3, px, py, depth);
+    const float xf = (float)x, yf = (float)(y + p.y_offset);
+    float vx = __builtin_fmaf(p.pos_m[0], xf, __builtin_fmaf(p.pos_m[1], yf, __builtin_fmaf(p.pos_m[2], depth, p.pos_m[3])));
+    float vy = __builtin_fmaf(p.pos_m[4], xf, __builtin_fmaf(p.pos_m[5], yf, __builtin_fmaf(p.pos_m[6], depth, p.pos_m[7])));
+    float vz = __builtin_fmaf(p.pos_m[8], xf, __builtin_fmaf(p.pos_m[9], yf, __builtin_fmaf(p.pos_m[10], depth, p.pos_m[11])));
+    float vw = __builtin_fmaf(p.pos_m[12], xf, __builtin_fmaf(p.pos_m[13], yf, __builtin_fmaf(p.pos_m[14], depth, p.pos_m[15])));
     float iw = rcp_(vw);
-    vx *= iw; vy *= iw; vz *= iw;
-    return f3{ mrow1(p.inv_view, 0, vx, vy, vz), mrow1(p.inv_view, 1, vx, vy, vz), mrow1(p.inv_view, 2, vx, vy, vz) };
+    Pos r;
+    r.D = f3{ vx * iw, vy * iw, vz * iw };
+    r.P = f3{ r.D.x + p.cam[0], r.D.y + p.cam[1], r.D.z + p.cam[2] };
+    return r;
 }
 
-DEV void setup_pixel(Px &q, const ShadeParams &p, f3 P, uint32_t u1, uint32_t u2, uint32_t u3)
+DEV void setup_pixel(Px &q, const ShadeParams &p, Pos pos, uint32_t u1, uint32_t u2, uint32_t u3)
 {
     const float k10 = 2.0f / 1023.0f, k8 = 1.0f / 255.0f;
     f3 nrm = { __builtin_fmaf((float)(u1 & 0x3FF), k10, -1.0f), __builtin_fmaf((float)((u1 >> 10) & 0x3FF), k10, -1.0f),
@@ -233,45 +259,57 @@ DEV void setup_pixel(Px &q, const ShadeParams &p, f3 P, uint32_t u1, uint32_t u2
     q.occ = (float)(u2 >> 24) * k8;
     float roughness = fmaxf((float)(u3 & 0xFF) * k8, 0.0001f);
     float m = (float)((u3 >> 8) & 0xFF) * k8;
-    q.P = P;
+    q.P = pos.P;
     float rn = rsq_(dot3(nrm, nrm));
     q.N = f3{ nrm.x * rn, nrm.y * rn, nrm.z * rn };
-    f3 tc = { p.cam[0] - q.P.x, p.cam[1] - q.P.y, p.cam[2] - q.P.z };
-    float rv = rsq_(dot3(tc, tc));
-    q.V = f3{ tc.x * rv, tc.y * rv, tc.z * rv };
+    float rv = -rsq_(dot3(pos.D, pos.D));
+    q.V = f3{ pos.D.x * rv, pos.D.y * rv, pos.D.z * rv };
     q.alpha = roughness * roughness;
     q.a2 = q.alpha * q.alpha;
     q.am1 = q.a2 - 1.0f;
-    q.NdotV = __builtin_amdgcn_fmed3f(dot3(q.N, q.V), 0.0001f, 1.0f);
+    q.NdotVraw = dot3(q.N, q.V);
+    q.NdotV = __builtin_amdgcn_fmed3f(q.NdotVraw, 0.0001f, 1.0f);
     q.sV = sqrt_(__builtin_fmaf(__builtin_fmaf(-q.a2, q.NdotV, q.NdotV), q.NdotV, q.a2));
     float om = 1.0f - m;
-    q.F0 = f3{ __builtin_fmaf(albedo.x, m, 0.04f * om), __builtin_fmaf(albedo.y, m, 0.04f * om), __builtin_fmaf(albedo.z, m, 0.04f * om) };
-    float f90 = sat((q.F0.x + q.F0.y + q.F0.z) * 16.5f);
-    q.dF = f3{ f90 - q.F0.x, f90 - q.F0.y, f90 - q.F0.z };
+    const f3 F0 = { __builtin_fmaf(albedo.x, m, 0.04f * om), __builtin_fmaf(albedo.y, m, 0.04f * om), __builtin_fmaf(albedo.z, m, 0.04f * om) };
+    const float f90 = sat((F0.x + F0.y + F0.z) * 16.5f);
     float ds = om * q.occ * (1.0f / PI_LIT);
     q.dif = f3{ albedo.x * ds, albedo.y * ds, albedo.z * ds };
-    q.tint = f3{ __builtin_fmaf(albedo.x, m, om) * q.occ, __builtin_fmaf(albedo.y, m, om) * q.occ, __builtin_fmaf(albedo.z, m, om) * q.occ };
+    const f3 tint = { __builtin_fmaf(albedo.x, m, om) * q.occ, __builtin_fmaf(albedo.y, m, om) * q.occ, __builtin_fmaf(albedo.z, m, om) * q.occ };
+    q.G0 = f3{ tint.x * F0.x, tint.y * F0.y, tint.z * F0.z };
+    q.G1 = f3{ tint.x * (f90 - F0.x), tint.y * (f90 - F0.y), tint.z * (f90 - F0.z) };
 }
 
-// light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow]
-DEV void eval_light(const Px &q, f3 L, f3 rad, f3 &res)
+// light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow].
+//   colour = dif + tint * (F0 + (f90 - F0) w^5) * D * Vis = dif + (G0 + G1 w^5) * DV
+DEV void eval_tail(const Px &q, float NdotL, float NdotH, float LdotH, f3 rad, f3 &res)
 {
-    f3 H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
-    float rh = rsq_(dot3(H, H));
-    float NdotL = sat(dot3(q.N, L));
-    float NdotH = sat(dot3(q.N, H) * rh);
-    float LdotH = sat(dot3(L, H) * rh);
     float x2 = NdotH * NdotH;
     float k = q.alpha * rcp_(__builtin_fmaf(x2, q.am1, 1.0f));          // alpha / ((1-x2) + x2*alpha^2)
     float sL = sqrt_(__builtin_fmaf(__builtin_fmaf(-q.a2, NdotL, NdotL), NdotL, q.a2));
     float den = __builtin_fmaf(NdotL, q.sV, q.NdotV * sL);               // GGXV + GGXL
     float DV = (k * k) * ((0.5f / PI_LIT) * rcp_(den));                  // D * Vis
     float w = 1.0f - LdotH, w2 = w * w, w5 = w2 * w2 * w;
-    float sx = __builtin_fmaf(q.dF.x, w5, q.F0.x) * DV, sy = __builtin_fmaf(q.dF.y, w5, q.F0.y) * DV, sz = __builtin_fmaf(q.dF.z, w5, q.F0.z) * DV;
-    float cx = __builtin_fmaf(sx, q.tint.x, q.dif.x), cy = __builtin_fmaf(sy, q.tint.y, q.dif.y), cz = __builtin_fmaf(sz, q.tint.z, q.dif.z);
+    float cx = __builtin_fmaf(__builtin_fmaf(q.G1.x, w5, q.G0.x), DV, q.dif.x);
+    float cy = __builtin_fmaf(__builtin_fmaf(q.G1.y, w5, q.G0.y), DV, q.dif.y);
+    float cz = __builtin_fmaf(__builtin_fmaf(q.G1.z, w5, q.G0.z), DV, q.dif.z);
     res.x = __builtin_fmaf(cx, rad.x * NdotL, res.x);
     res.y = __builtin_fmaf(cy, rad.y * NdotL, res.y);
     res.z = __builtin_fmaf(cz, rad.z * NdotL, res.z);
+}
+// general L (directional lights are not normalised by the shader, inc_structs.glsl:12-16)
+DEV void eval_light(const Px &q, f3 L, f3 rad, f3 &res)
+{
+    f3 H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
+    float rh = rsq_(dot3(H, H));
+    eval_tail(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), rad, res);
+}
+// |L| = 1 (point lights, normalised here):  |L+V|^2 = 2 + 2 L.V,  N.H = (N.L + N.V) / |L+V|,  L.H = (1 + L.V) / |L+V|
+DEV void eval_light_unit(const Px &q, f3 L, f3 rad, f3 &res)
+{
+    float nl = dot3(q.N, L), lv = dot3(L, q.V);
+    float rh = rsq_(__builtin_fmaf(2.0f, lv, 2.0f));
+    eval_tail(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(__builtin_fmaf(lv, rh, rh)), rad, res);
 }
 
 DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
@@ -289,19 +327,30 @@ DEV float point_d2(const Px &q, v4f a, f3 &Lv)
 DEV float point_r2(v4f a) { return a.w; }   // prepared record carries r*r
 DEV v4f point_rec_a(const ShadeParams &p, uint32_t l) { return ldu(p.point_prep, 2 * l); }
 DEV v4f point_rec_b(const ShadeParams &p, uint32_t l) { return ldu(p.point_prep, 2 * l + 1); }
-DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
+DEV v4f point_rec_a_v(const ShadeParams &p, uint32_t l) { return ((const v4f *)p.point_prep)[2 * l]; }   // per-lane (vector) fetch
+DEV v4f point_rec_b_v(const ShadeParams &p, uint32_t l) { return ((const v4f *)p.point_prep)[2 * l + 1]; }
+DEV bool point_test(const Px &q, v4f a, f3 &Lv, float &d2)
 {
-    f3 Lv;
-    float d2 = point_d2(q, a, Lv);
-    bool on = d2 < a.w && q.occ > 0.0f;
-    if (__builtin_amdgcn_ballot_w64(on) == 0) return;           // wave-uniform early out
+    d2 = point_d2(q, a, Lv);
+    return d2 < a.w && q.occ > 0.0f;
+}
+DEV void point_eval(const Px &q, v4f a, v4f b, f3 Lv, float d2, bool on, f3 &res)
+{
     float inv = rsq_(fmaxf(d2, 1e-12f));
     f3 L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
     float qq = d2 * b.w, w = sat(__builtin_fmaf(-qq, qq, 1.0f));
     float att = on ? (w * w) * rcp_(d2 + 1e-4f) : 0.0f;         // select, not multiply: 0 stays 0 for non-finite BRDF values
     f3 t = { 0.0f, 0.0f, 0.0f };
-    eval_light(q, L, f3{ b.x * att, b.y * att, b.z * att }, t);
+    eval_light_unit(q, L, f3{ b.x * att, b.y * att, b.z * att }, t);
     if (on) { res.x += t.x; res.y += t.y; res.z += t.z; }
+}
+DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
+{
+    f3 Lv;
+    float d2;
+    const bool on = point_test(q, a, Lv, d2);
+    if (__builtin_amdgcn_ballot_w64(on) == 0) return;           // wave-uniform early out
+    point_eval(q, a, b, Lv, d2, on, res);
 }
 DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t u2, f3 &res)
 {
@@ -348,10 +397,22 @@ DEV ShadowTap shadow_tap(f3 P, const ShadeParams &p)
     t.zc = zr - p.shadow_bias;
     return t;
 }
+struct __attribute__((packed, aligned(4))) Row3 { float a, b, c; };
 DEV float pcf_direct(const ShadowTap &t, const ShadeParams &p)
 {
     if (!t.inside) return 1.0f;
-    int S = (int)p.shadow_size, cnt = 0;
+    const int S = (int)p.shadow_size;
+    int cnt = 0;
+    const bool border = t.tx < 1 || t.ty < 1 || t.tx > S - 2 || t.ty > S - 2;
+    if (__builtin_amdgcn_ballot_w64(border) == 0) {
+        // interior for every active lane: clamp-to-edge is the identity, a row of taps is 3 consecutive floats
+        const float *q = p.shadow_map + (size_t)(t.ty - 1) * S + (t.tx - 1);
+        Row3 r0, r1, r2;
+        __builtin_memcpy(&r0, q, 12); __builtin_memcpy(&r1, q + S, 12); __builtin_memcpy(&r2, q + 2 * (size_t)S, 12);
+        cnt = (t.zc <= r0.a) + (t.zc <= r0.b) + (t.zc <= r0.c) + (t.zc <= r1.a) + (t.zc <= r1.b) + (t.zc <= r1.c) +
+              (t.zc <= r2.a) + (t.zc <= r2.b) + (t.zc <= r2.c);
+        return pcf_result(cnt);
+    }
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++) {
         int yy = min(max(t.ty + dy, 0), S - 1);
@@ -473,17 +534,22 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
 // 256-thread workgroup is four independent waves on four horizontally adjacent tiles (so
 // the workgroup reads whole 256-byte row segments).  Lane l owns pixels
 // (l & 15, (l >> 4) + 4 j), j = 0..3.
-//  1. all 16 texel loads of the lane are issued at once, with the first 64 light records;
-//  2. world positions of the 4 pixels -> the tile's AABB of lit pixels by DPP row
+//  1. the tile's 4 planes x 256 texels go HBM -> LDS by 16 LDS-DMA loads per wave
+//     (global_load_lds_dword: no staging registers, each texel fetched exactly once), issued
+//     together with the first 64 cull records;
+//  2. world positions of the lane's 4 pixels -> the tile's AABB of lit pixels by DPP row
 //     reductions + v_readlane (no LDS round trip);
-//  3. point lights, CHUNK at a time: 64 lights per step are tested against the AABB and
-//     survivors appended to the wave's LDS list with ballot + mbcnt prefix, so the list
-//     stays in ascending light order and the summation order equals the brute-force
-//     loop's (culled == unculled, bit for bit);
-//  4. shadow: when the tile's texel rectangle (+1 apron) fits, the wave stages it in LDS
-//     with clamp-to-edge baked in and the 3x3 taps read LDS;
-//  5. four passes (j) shade 64 pixels each: directional lights, then the LDS list with
-//     light records fetched through the scalar cache one entry ahead.
+//  3. point lights, CHUNK at a time: 64 lights per step (next step's records in flight) are
+//     tested against the AABB and survivors appended to the wave's LDS list with ballot +
+//     mbcnt prefix, so the list stays in ascending light order and the summation order
+//     equals the brute-force loop's (culled == unculled, bit for bit);
+//  4. shadow (optional staging): when the tile's texel rectangle (+1 apron) fits, the wave
+//     stages it in LDS with clamp-to-edge baked in and the 3x3 taps read LDS;
+//  5. the list is consumed 64 entries at a time: lane k fetches entry k's light record into
+//     8 VGPRs, and the per-light loop broadcasts record k with v_readlane (no memory latency
+//     inside the loop; the radiance half is only broadcast when some lane is in range);
+//  6. four passes (j) shade 64 pixels each from the LDS texels: directional lights, then
+//     the list.
 // ---------------------------------------------------------------------------------
 template <int CTRL> DEV float dpp_f(float v)
 {
@@ -531,17 +597,42 @@ DEV float box_d2(v4f a, f3 lo, f3 hi)
 #endif
 }
 
+// Per-wave LDS carve of k_tiled (bytes), shared by the launcher and the kernel.
+struct TiledLds { uint32_t list, stash, shadow, per_wave; };
+static __host__ __device__ __forceinline__ TiledLds tiled_lds(uint32_t n_point, bool stage)
+{
+    TiledLds l;
+    const uint32_t cap = n_point < (uint32_t)CHUNK ? ((n_point + 63u) & ~63u) : (uint32_t)CHUNK;   // list entries (u16)
+    l.list = 4096u;                                                   // after the 4 x 4 x 64 texel dwords
+    l.stash = l.list + ((cap * 2u + 15u) & ~15u);
+    l.shadow = l.stash + (n_point > (uint32_t)CHUNK ? 768u * 4u : 0u);
+    l.per_wave = l.shadow + (stage ? (uint32_t)SH_CAP * 4u : 0u);
+    return l;
+}
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+DEV v4f bcast4(v4f v, int k)
+{
+    return v4f{ lane_f(v.x, k), lane_f(v.y, k), lane_f(v.z, k), lane_f(v.w, k) };
+}
+
 template <int FMT>
 __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    // dynamic LDS: [4 lists: CHUNK u16] [4 result stashes: 3 x 256 f32, only if n_point > CHUNK] [4 shadow rects: SH_CAP f32]
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t n_chunks = p.n_point ? (p.n_point + CHUNK - 1) / CHUNK : 1;
     const uint32_t wpb = blockDim.x >> 6;               // waves (= tiles) per workgroup
-    uint16_t *s_list = (uint16_t *)s_raw + wv * CHUNK;
-    float *s_res = (float *)(s_raw + wpb * CHUNK * sizeof(uint16_t)) + wv * 768;
-    float *s_shadow = (float *)(s_raw + wpb * CHUNK * sizeof(uint16_t) + (n_chunks > 1 ? wpb * 768 * sizeof(float) : 0)) + wv * SH_CAP;
+    const bool do_shadow = p.has_shadow && p.n_dir > 0;
+    const bool stage = do_shadow && p.shadow_lds;
+    const TiledLds L = tiled_lds(p.n_point, stage);
+    unsigned char *s_wave = s_raw + wv * L.per_wave;
+    uint32_t *s_tex = (uint32_t *)s_wave;               // [plane: normal, albedo, rm, depth][j][lane]
+    uint16_t *s_list = (uint16_t *)(s_wave + L.list);
+    float *s_res = (float *)(s_wave + L.stash);
+    float *s_shadow = (float *)(s_wave + L.shadow);
 
     // Workgroups keep dispatch (round-robin over XCDs) order: neighbouring tile groups land on
     // different XCDs, which balances the heavy (many-light) screen regions over the chip.  Giving
@@ -551,29 +642,38 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
     const uint32_t tyi = blk / bpr, txi = (blk - tyi * bpr) * wpb + wv;
     if (txi >= p.tiles_x) return;                       // whole wave; nothing below synchronises across waves
 
-    // ---- 1/2. AABB of lit pixels + shadow texel rectangle.  Needs only depth and occlusion of the
-    //          256 pixels; nothing of it stays in registers (the passes re-fetch their texels, L2 hits).
+    // ---- 1. HBM -> LDS, coordinates clamped (not branched) so the loads are straight-line ----
     const uint32_t x = txi * TILE + (lane & 15u), y0 = tyi * TILE + (lane >> 4);
     const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
     const bool xin = x < p.width;
+    {
+        size_t i[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) i[j] = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
+#pragma unroll
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.albedo + i[j]), (lptr_t)(s_tex + (4 + j) * 64), 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.normal + i[j]), (lptr_t)(s_tex + (0 + j) * 64), 4, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.rm + i[j]), (lptr_t)(s_tex + (8 + j) * 64), 4, 0, 0);
+    }
     const v4f *cull = (const v4f *)p.point_cull;
+    v4f c_first = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (lane < p.n_point) c_first = cull[lane];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes are ordered only by this wave's vmcnt
+
+    // ---- 2. AABB of lit pixels + shadow texel rectangle ----
     const float INF = __builtin_inff();
     f3 lo = { INF, INF, INF }, hi = { -INF, -INF, -INF };
-    const bool do_shadow = p.has_shadow && p.n_dir > 0;
-    const bool stage = do_shadow && p.shadow_lds;
     int x0 = 0x7FFFFFFF, x1 = -0x7FFFFFFF, yy0 = 0x7FFFFFFF, yy1 = -0x7FFFFFFF;
     if (p.n_point > 0 || stage) {
-        uint32_t w2[4];
-        float dz[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {                   // clamped, not branched: straight-line loads
-            const size_t i = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
-            w2[j] = p.albedo[i]; dz[j] = p.depth[i];
-        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const f3 P = pixel_position(p, x, y0 + 4 * j, dz[j]);
-            const bool lit = xin && (y0 + 4 * j) <= ylast && (w2[j] >> 24) != 0;   // occlusion 0 => every point-light term is exactly 0
+            const uint32_t w2 = s_tex[(4 + j) * 64 + lane];
+            const f3 P = pixel_position(p, x, y0 + 4 * j, __uint_as_float(s_tex[(12 + j) * 64 + lane])).P;
+            const bool lit = xin && (y0 + 4 * j) <= ylast && (w2 >> 24) != 0;   // occlusion 0 => every point-light term is exactly 0
             if (lit) {
                 lo.x = fminf(lo.x, P.x); lo.y = fminf(lo.y, P.y); lo.z = fminf(lo.z, P.z);
                 hi.x = fmaxf(hi.x, P.x); hi.y = fmaxf(hi.y, P.y); hi.z = fmaxf(hi.z, P.z);
@@ -620,10 +720,13 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
         const uint32_t base = ch * CHUNK, end = min(base + (uint32_t)CHUNK, p.n_point);
         uint32_t cnt = 0;
         if (any_lit) {
+            v4f c = c_first;
+            if (ch > 0) { c = v4f{ 0.0f, 0.0f, 0.0f, 0.0f }; if (base + lane < end) c = cull[base + lane]; }
+#pragma unroll 1
             for (uint32_t b0 = base; b0 < end; b0 += 64) {
                 const uint32_t li = b0 + lane;
-                v4f c = { 0.0f, 0.0f, 0.0f, 0.0f };
-                if (li < end) c = cull[li];
+                v4f cn = { 0.0f, 0.0f, 0.0f, 0.0f };
+                if (li + 64 < end) cn = cull[li + 64];                 // next step's records fly during this step
                 const bool pass = li < end && box_d2(c, lo, hi) < c.w * c.w;
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                 if (pass) {
@@ -631,26 +734,38 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
                     s_list[pos] = (uint16_t)(li - base);
                 }
                 cnt += (uint32_t)__builtin_popcountll(m);
+                c = cn;
             }
             __builtin_amdgcn_wave_barrier();
         }
         total += cnt;
 
-        // ---- 5. four passes of 64 pixels; pass j+1's texels are requested before pass j is shaded ----
-        struct Texel { uint32_t u1, u2, u3; float depth; };
-        auto fetch = [&](uint32_t j) {
-            const size_t i = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
-            return Texel{ p.normal[i], p.albedo[i], p.rm[i], p.depth[i] };
+        // ---- 5. lane k <- record of list entry kb + k ----
+        auto gather = [&](uint32_t kb, v4f &ra, v4f &rb) {
+            const uint32_t li = base + s_list[min(kb + lane, cnt - 1)];
+            ra = point_rec_a_v(p, li); rb = point_rec_b_v(p, li);
         };
-        Texel t = fetch(0);
+        v4f ra0 = { 0.0f, 0.0f, 0.0f, 0.0f }, rb0 = ra0;
+        if (cnt) gather(0, ra0, rb0);
+
+        // ---- 6. four passes of 64 pixels ----
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; j++) {
-            const Texel tn = fetch(min(j + 1, 3u));
             const uint32_t y = y0 + 4 * j;
-            const uint32_t w2 = t.u2;
+            const uint32_t u1 = s_tex[(0 + j) * 64 + lane], w2 = s_tex[(4 + j) * 64 + lane], u3 = s_tex[(8 + j) * 64 + lane];
+            const float depth = __uint_as_float(s_tex[(12 + j) * 64 + lane]);
             const bool inbj = xin && y <= ylast, litj = inbj && (w2 >> 24) != 0;
+#if !MIL_STRICT
+            // occlusion 0 (cleared G-buffer, render/mod.rs:129-131: sky / background) multiplies every term of
+            // fs_deferred_lighting.glsl:63 and of the extensions: the pixel is exactly 0.  When none of the
+            // pass's 64 pixels is lit the wave writes the zeros and skips the shading altogether.
+            if (__builtin_amdgcn_ballot_w64(litj) == 0) {
+                if (ch + 1 == n_chunks && inbj) store_pixel<FMT>(p, x, y, f3{ 0.0f, 0.0f, 0.0f });
+                continue;
+            }
+#endif
             Px q;
-            setup_pixel(q, p, pixel_position(p, x, y, t.depth), t.u1, w2, t.u3);
+            setup_pixel(q, p, pixel_position(p, x, y, depth), u1, w2, u3);
             f3 r = { 0.0f, 0.0f, 0.0f };
             if (ch == 0) {
                 float shadow = 1.0f;
@@ -675,16 +790,23 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
                 r = f3{ s_res[j * 64 + lane], s_res[256 + j * 64 + lane], s_res[512 + j * 64 + lane] };
             }
             if (cnt) {
-                // software pipeline: record k+1 is requested (scalar cache) while record k is evaluated
-                uint32_t li = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[0]);
-                v4f a = point_rec_a(p, li), bb = point_rec_b(p, li);
+                v4f ra = ra0, rb = rb0;
+                uint32_t kb = 0;
 #pragma unroll 1
-                for (uint32_t k = 0; k < cnt; k++) {
-                    const uint32_t kn = min(k + 1, cnt - 1);
-                    const uint32_t ln = base + (uint32_t)__builtin_amdgcn_readfirstlane((int)s_list[kn]);
-                    const v4f an = point_rec_a(p, ln), bn = point_rec_b(p, ln);
-                    add_point(q, a, bb, r);
-                    a = an; bb = bn;
+                for (;;) {
+                    const uint32_t n = min(64u, cnt - kb);
+#pragma unroll 1
+                    for (uint32_t k = 0; k < n; k++) {
+                        const v4f a = bcast4(ra, (int)k);
+                        f3 Lv;
+                        float d2;
+                        const bool on = point_test(q, a, Lv, d2);
+                        if (__builtin_amdgcn_ballot_w64(on) == 0) continue;      // wave-uniform: nobody in range
+                        point_eval(q, a, bcast4(rb, (int)k), Lv, d2, on, r);
+                    }
+                    kb += 64;
+                    if (kb >= cnt) break;
+                    gather(kb, ra, rb);
                 }
             }
             if (ch + 1 == n_chunks) {
@@ -693,7 +815,6 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
             } else {
                 s_res[j * 64 + lane] = r.x; s_res[256 + j * 64 + lane] = r.y; s_res[512 + j * 64 + lane] = r.z;
             }
-            t = tn;
         }
         __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next chunk only after these reads were issued
     }
@@ -760,8 +881,7 @@ void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s)
 {
     const uint32_t wpb = (p.tune & 2u) ? 1 : ((p.tune & 4u) ? 2 : 4);
     dim3 block(64 * wpb), grid(((p.tiles_x + wpb - 1) / wpb) * p.tiles_y);
-    const size_t lds = wpb * (CHUNK * sizeof(uint16_t) + (p.n_point > (uint32_t)CHUNK ? 768 * sizeof(float) : 0) +
-                              ((p.has_shadow && p.shadow_lds && p.n_dir) ? SH_CAP * sizeof(float) : 0));
+    const size_t lds = (size_t)wpb * tiled_lds(p.n_point, p.has_shadow && p.shadow_lds && p.n_dir).per_wave;
     switch (fmt) {
     case FMT_HDR: hipLaunchKernelGGL(k_tiled<FMT_HDR>, grid, block, lds, s, p); break;
     case FMT_LDR: hipLaunchKernelGGL(k_tiled<FMT_LDR>, grid, block, lds, s, p); break;

@@ -18,7 +18,8 @@ struct ShadeParams {
     // FrameMatrixData subset read by the lighting shader (fs_deferred_lighting.glsl:34-36,59)
     float inv_proj[16], inv_view[16], cam[3];
     float res_x, res_y;     // push_constants.resolution
-    float sx, ox, sy, oy;   // fast path: clip.xy = (x, y_global) * s + o  ==  ((x+0.5)/res)*2-1
+    float sx, ox, sy, oy;   // clip.xy = (x, y_global) * s + o  ==  ((x+0.5)/res)*2-1
+    float pos_m[16];        // fast path: rows 0-2 = inv_view * inv_proj * pixel->clip, row 3 = w row of inv_proj * pixel->clip
     // staged light arrays (device): each record = 2 float4
     uint32_t n_dir, n_point;
     float dir_inline[MIL_DIR_INLINE][8]; // first records in this launch's mode layout (raw if strict, else prepared)
