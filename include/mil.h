@@ -165,6 +165,9 @@ int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
 /* After a culled mil_light_ex: per-tile light-list lengths of that call are written to
  * `counts` (DEVICE, tiles_x * tiles_y uint32) when set before the call; NULL disables. */
 int mil_set_tile_count_buffer(mil_ctx *ctx, uint32_t *counts);
+/* Diagnostics: per tile {start, end} in 100 MHz ticks (low 32 bits), list length, HW_ID of the shading wave.
+ * stamps: DEVICE, 4 * tiles_x * tiles_y uint32; NULL disables. */
+int mil_set_tile_stamp_buffer(mil_ctx *ctx, uint32_t *stamps);
 
 int mil_sync(mil_ctx *ctx, void *stream);
 int mil_last_hip_error(const mil_ctx *ctx);

@@ -43,6 +43,7 @@ struct mil_ctx {
     hipStream_t copy_stream = nullptr;
     uint8_t *lut = nullptr; // device: lut11 then lut10
     uint32_t *tile_counts = nullptr;
+    uint32_t *tile_stamps = nullptr;
     uint32_t tune = 0;
     uint32_t k1_rows = 1;   // K1 pixels per lane: 1 or 4 (env MIL_K1_ROWS overrides; tuning only)
     int last_hip = 0;
@@ -206,6 +207,13 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
     }
     p.tiles_x = (gb->width + MIL_TILE - 1) / MIL_TILE;
     p.tiles_y = (gb->height + MIL_TILE - 1) / MIL_TILE;
+    {   // golden-ratio row stride, made coprime with the row count
+        auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
+        uint32_t m = (uint32_t)(0.6180339887 * p.tiles_y + 0.5);
+        if (m < 1) m = 1;
+        while (gcd(m, p.tiles_y) != 1) m++;
+        p.row_mul = m % p.tiles_y ? m % p.tiles_y : 1;
+    }
 }
 
 int finish(mil_ctx *c, Slot *sl, hipStream_t s)
@@ -305,6 +313,13 @@ int mil_set_tile_count_buffer(mil_ctx *c, uint32_t *counts)
     return MIL_OK;
 }
 
+int mil_set_tile_stamp_buffer(mil_ctx *c, uint32_t *stamps)
+{
+    if (!c) return MIL_ERR_BAD_ARG;
+    c->tile_stamps = stamps;
+    return MIL_OK;
+}
+
 int mil_sync(mil_ctx *c, void *stream)
 {
     if (!c) return MIL_ERR_BAD_ARG;
@@ -359,6 +374,7 @@ int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
     if (tiled) {
         p.tile_counts = c->tile_counts;
+        p.tile_stamps = c->tile_stamps;
         if (strict) mil::strict::launch_tiled((int)fmt, p, s);
         else mil::fast::launch_tiled((int)fmt, p, s);
     } else {

@@ -32,7 +32,8 @@ constexpr int SH_CAP = 576;          // floats of shadow map staged in LDS per w
 
 enum { FMT_HDR = 0, FMT_LDR = 1, FMT_SRGB8 = 2, FMT_SRGB8_VIA_LDR = 3 };
 
-struct f3 { float x, y, z; };
+template <typename T> struct V3 { T x, y, z; };
+typedef V3<float> f3;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
@@ -65,19 +66,26 @@ DEV DirRec dir_rec(const ShadeParams &p, uint32_t l)
 // ---------------------------------------------------------------------------------
 // per-pixel state
 // ---------------------------------------------------------------------------------
+#if MIL_STRICT
 struct Px {
     f3 N, V, P;
     float occ;
-#if MIL_STRICT
     f3 albedo;
     float alpha, metallic;
-#else
-    float alpha, a2, am1, NdotV, sV;   // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
-    float NdotVraw;                    // dot(N, V) before the clamp (point lights: N.H = (N.L + N.V) / |L + V|)
-    f3 G0, G1;                         // tint * F0, tint * (f90 - F0), tint = ((1-m) + albedo*m)*occ
-    f3 dif;                            // albedo/PI*(1-m)*occ
-#endif
 };
+#else
+// T = float: one pixel per lane (K1); T = v2f: two pixels per lane, packed FP32 (K2)
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+template <typename T> struct PxT {
+    V3<T> N, V, P;
+    T occ;
+    T alpha, a2, am1, NdotV, sV;       // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
+    T NdotVraw;                        // dot(N, V) before the clamp (point lights: N.H = (N.L + N.V) / |L + V|)
+    V3<T> G0, G1;                      // tint * F0, tint * (f90 - F0), tint = ((1-m) + albedo*m)*occ
+    V3<T> dif;                         // albedo/PI*(1-m)*occ
+};
+#endif
 
 #if MIL_STRICT
 // ---- literal transcription, one IEEE operation per GLSL operator ----
@@ -221,102 +229,135 @@ DEV uint32_t srgb8_direct(float c)
 
 #else
 // ---- fast path: same formulas, light-invariant terms hoisted, hardware rcp/rsq/sqrt ----
+// Everything per-pixel is a template over T: float (one pixel per lane) or v2f (two pixels per lane;
+// hipcc lowers the v2f arithmetic to v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, one issue slot for
+// both pixels, and the two pixels give every wave two independent dependency chains).
 DEV float rcp_(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV float rsq_(float x) { return __builtin_amdgcn_rsqf(x); }
 DEV float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
-DEV float dot3(f3 a, f3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+DEV v2f rcp_(v2f x) { return v2f{ rcp_(x.x), rcp_(x.y) }; }
+DEV v2f rsq_(v2f x) { return v2f{ rsq_(x.x), rsq_(x.y) }; }
+DEV v2f sqrt_(v2f x) { return v2f{ sqrt_(x.x), sqrt_(x.y) }; }
+DEV v2f sat(v2f x) { return v2f{ sat(x.x), sat(x.y) }; }
+DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+DEV v2f fma_(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+DEV float max_(float a, float b) { return fmaxf(a, b); }
+DEV v2f max_(v2f a, v2f b) { return v2f{ fmaxf(a.x, b.x), fmaxf(a.y, b.y) }; }
+DEV float med3_(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+DEV v2f med3_(v2f a, float lo, float hi) { return v2f{ med3_(a.x, lo, hi), med3_(a.y, lo, hi) }; }
+DEV float tof(uint32_t u) { return (float)u; }
+DEV v2f tof(v2u u) { return __builtin_convertvector(u, v2f); }
+template <typename T> DEV T dot3(V3<T> a, V3<T> b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 DEV float mrow1(const float *m, int r, float x, float y, float z)   // w == 1
 {
     return __builtin_fmaf(m[0 + r], x, __builtin_fmaf(m[4 + r], y, __builtin_fmaf(m[8 + r], z, m[12 + r])));
 }
+typedef PxT<float> Px;
+typedef PxT<v2f> Px2;
 
 // PositionFromDepth with the two matrix products and the pixel -> clip map folded on the host
 // (mil_api.cpp fill_common, in double).  The folded matrix carries inv_view's translation MINUS the
 // camera position, so what comes out is D = P - cameraPosition without the cancellation the literal
 // form has near the camera (V = normalize(-D)); P = D + cameraPosition.
 //   D = (A . (x, y_global, depth, 1)).xyz / (A . (...)).w
-struct Pos { f3 P, D; };
-DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+template <typename T> struct PosT { V3<T> P, D; };
+template <typename T> DEV PosT<T> pixel_position_t(const ShadeParams &p, T xf, T yf, T depth)
 {
-    const float xf = (float)x, yf = (float)(y + p.y_offset);
-    float vx = __builtin_fmaf(p.pos_m[0], xf, __builtin_fmaf(p.pos_m[1], yf, __builtin_fmaf(p.pos_m[2], depth, p.pos_m[3])));
-    float vy = __builtin_fmaf(p.pos_m[4], xf, __builtin_fmaf(p.pos_m[5], yf, __builtin_fmaf(p.pos_m[6], depth, p.pos_m[7])));
-    float vz = __builtin_fmaf(p.pos_m[8], xf, __builtin_fmaf(p.pos_m[9], yf, __builtin_fmaf(p.pos_m[10], depth, p.pos_m[11])));
-    float vw = __builtin_fmaf(p.pos_m[12], xf, __builtin_fmaf(p.pos_m[13], yf, __builtin_fmaf(p.pos_m[14], depth, p.pos_m[15])));
-    float iw = rcp_(vw);
-    Pos r;
-    r.D = f3{ vx * iw, vy * iw, vz * iw };
-    r.P = f3{ r.D.x + p.cam[0], r.D.y + p.cam[1], r.D.z + p.cam[2] };
+    const float *m = p.pos_m;
+    T vx = fma_((T)m[0], xf, fma_((T)m[1], yf, fma_((T)m[2], depth, (T)m[3])));
+    T vy = fma_((T)m[4], xf, fma_((T)m[5], yf, fma_((T)m[6], depth, (T)m[7])));
+    T vz = fma_((T)m[8], xf, fma_((T)m[9], yf, fma_((T)m[10], depth, (T)m[11])));
+    T vw = fma_((T)m[12], xf, fma_((T)m[13], yf, fma_((T)m[14], depth, (T)m[15])));
+    T iw = rcp_(vw);
+    PosT<T> r;
+    r.D = V3<T>{ vx * iw, vy * iw, vz * iw };
+    r.P = V3<T>{ r.D.x + p.cam[0], r.D.y + p.cam[1], r.D.z + p.cam[2] };
     return r;
 }
+typedef PosT<float> Pos;
+DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+{
+    return pixel_position_t<float>(p, (float)x, (float)(y + p.y_offset), depth);
+}
 
-DEV void setup_pixel(Px &q, const ShadeParams &p, Pos pos, uint32_t u1, uint32_t u2, uint32_t u3)
+// U = uint32_t / v2u: the three packed G-buffer texels of the pixel(s)
+template <typename T, typename U> DEV void setup_pixel_t(PxT<T> &q, const PosT<T> &pos, U u1, U u2, U u3)
 {
     const float k10 = 2.0f / 1023.0f, k8 = 1.0f / 255.0f;
-    f3 nrm = { __builtin_fmaf((float)(u1 & 0x3FF), k10, -1.0f), __builtin_fmaf((float)((u1 >> 10) & 0x3FF), k10, -1.0f),
-               __builtin_fmaf((float)((u1 >> 20) & 0x3FF), k10, -1.0f) };
-    f3 albedo = { (float)(u2 & 0xFF) * k8, (float)((u2 >> 8) & 0xFF) * k8, (float)((u2 >> 16) & 0xFF) * k8 };
-    q.occ = (float)(u2 >> 24) * k8;
-    float roughness = fmaxf((float)(u3 & 0xFF) * k8, 0.0001f);
-    float m = (float)((u3 >> 8) & 0xFF) * k8;
+    V3<T> nrm = { fma_(tof(u1 & 0x3FFu), (T)k10, (T)-1.0f), fma_(tof((u1 >> 10) & 0x3FFu), (T)k10, (T)-1.0f),
+                  fma_(tof((u1 >> 20) & 0x3FFu), (T)k10, (T)-1.0f) };
+    V3<T> albedo = { tof(u2 & 0xFFu) * k8, tof((u2 >> 8) & 0xFFu) * k8, tof((u2 >> 16) & 0xFFu) * k8 };
+    q.occ = tof(u2 >> 24) * k8;
+    T roughness = max_(tof(u3 & 0xFFu) * k8, (T)0.0001f);
+    T m = tof((u3 >> 8) & 0xFFu) * k8;
     q.P = pos.P;
-    float rn = rsq_(dot3(nrm, nrm));
-    q.N = f3{ nrm.x * rn, nrm.y * rn, nrm.z * rn };
-    float rv = -rsq_(dot3(pos.D, pos.D));
-    q.V = f3{ pos.D.x * rv, pos.D.y * rv, pos.D.z * rv };
+    T rn = rsq_(dot3(nrm, nrm));
+    q.N = V3<T>{ nrm.x * rn, nrm.y * rn, nrm.z * rn };
+    T rv = -rsq_(dot3(pos.D, pos.D));
+    q.V = V3<T>{ pos.D.x * rv, pos.D.y * rv, pos.D.z * rv };
     q.alpha = roughness * roughness;
     q.a2 = q.alpha * q.alpha;
     q.am1 = q.a2 - 1.0f;
     q.NdotVraw = dot3(q.N, q.V);
-    q.NdotV = __builtin_amdgcn_fmed3f(q.NdotVraw, 0.0001f, 1.0f);
-    q.sV = sqrt_(__builtin_fmaf(__builtin_fmaf(-q.a2, q.NdotV, q.NdotV), q.NdotV, q.a2));
-    float om = 1.0f - m;
-    const f3 F0 = { __builtin_fmaf(albedo.x, m, 0.04f * om), __builtin_fmaf(albedo.y, m, 0.04f * om), __builtin_fmaf(albedo.z, m, 0.04f * om) };
-    const float f90 = sat((F0.x + F0.y + F0.z) * 16.5f);
-    float ds = om * q.occ * (1.0f / PI_LIT);
-    q.dif = f3{ albedo.x * ds, albedo.y * ds, albedo.z * ds };
-    const f3 tint = { __builtin_fmaf(albedo.x, m, om) * q.occ, __builtin_fmaf(albedo.y, m, om) * q.occ, __builtin_fmaf(albedo.z, m, om) * q.occ };
-    q.G0 = f3{ tint.x * F0.x, tint.y * F0.y, tint.z * F0.z };
-    q.G1 = f3{ tint.x * (f90 - F0.x), tint.y * (f90 - F0.y), tint.z * (f90 - F0.z) };
+    q.NdotV = med3_(q.NdotVraw, 0.0001f, 1.0f);
+    q.sV = sqrt_(fma_(fma_(-q.a2, q.NdotV, q.NdotV), q.NdotV, q.a2));
+    T om = 1.0f - m;
+    const V3<T> F0 = { fma_(albedo.x, m, 0.04f * om), fma_(albedo.y, m, 0.04f * om), fma_(albedo.z, m, 0.04f * om) };
+    const T f90 = sat((F0.x + F0.y + F0.z) * 16.5f);
+    T ds = om * q.occ * (1.0f / PI_LIT);
+    q.dif = V3<T>{ albedo.x * ds, albedo.y * ds, albedo.z * ds };
+    const V3<T> tint = { fma_(albedo.x, m, om) * q.occ, fma_(albedo.y, m, om) * q.occ, fma_(albedo.z, m, om) * q.occ };
+    q.G0 = V3<T>{ tint.x * F0.x, tint.y * F0.y, tint.z * F0.z };
+    q.G1 = V3<T>{ tint.x * (f90 - F0.x), tint.y * (f90 - F0.y), tint.z * (f90 - F0.z) };
+}
+DEV void setup_pixel(Px &q, const ShadeParams &, Pos pos, uint32_t u1, uint32_t u2, uint32_t u3)
+{
+    setup_pixel_t<float, uint32_t>(q, pos, u1, u2, u3);
 }
 
 // light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow].
 //   colour = dif + tint * (F0 + (f90 - F0) w^5) * D * Vis = dif + (G0 + G1 w^5) * DV
-DEV void eval_tail(const Px &q, float NdotL, float NdotH, float LdotH, f3 rad, f3 &res)
+template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T LdotH, V3<T> rad, V3<T> &res)
 {
-    float x2 = NdotH * NdotH;
-    float k = q.alpha * rcp_(__builtin_fmaf(x2, q.am1, 1.0f));          // alpha / ((1-x2) + x2*alpha^2)
-    float sL = sqrt_(__builtin_fmaf(__builtin_fmaf(-q.a2, NdotL, NdotL), NdotL, q.a2));
-    float den = __builtin_fmaf(NdotL, q.sV, q.NdotV * sL);               // GGXV + GGXL
-    float DV = (k * k) * ((0.5f / PI_LIT) * rcp_(den));                  // D * Vis
-    float w = 1.0f - LdotH, w2 = w * w, w5 = w2 * w2 * w;
-    float cx = __builtin_fmaf(__builtin_fmaf(q.G1.x, w5, q.G0.x), DV, q.dif.x);
-    float cy = __builtin_fmaf(__builtin_fmaf(q.G1.y, w5, q.G0.y), DV, q.dif.y);
-    float cz = __builtin_fmaf(__builtin_fmaf(q.G1.z, w5, q.G0.z), DV, q.dif.z);
-    res.x = __builtin_fmaf(cx, rad.x * NdotL, res.x);
-    res.y = __builtin_fmaf(cy, rad.y * NdotL, res.y);
-    res.z = __builtin_fmaf(cz, rad.z * NdotL, res.z);
+    T x2 = NdotH * NdotH;
+    T k = q.alpha * rcp_(fma_(x2, q.am1, (T)1.0f));                      // alpha / ((1-x2) + x2*alpha^2)
+    T sL = sqrt_(fma_(fma_(-q.a2, NdotL, NdotL), NdotL, q.a2));
+    T den = fma_(NdotL, q.sV, q.NdotV * sL);                             // GGXV + GGXL
+    T DV = (k * k) * ((0.5f / PI_LIT) * rcp_(den));                      // D * Vis
+    T w = 1.0f - LdotH, w2 = w * w, w5 = w2 * w2 * w;
+    T cx = fma_(fma_(q.G1.x, w5, q.G0.x), DV, q.dif.x);
+    T cy = fma_(fma_(q.G1.y, w5, q.G0.y), DV, q.dif.y);
+    T cz = fma_(fma_(q.G1.z, w5, q.G0.z), DV, q.dif.z);
+    res.x = fma_(cx, rad.x * NdotL, res.x);
+    res.y = fma_(cy, rad.y * NdotL, res.y);
+    res.z = fma_(cz, rad.z * NdotL, res.z);
 }
 // general L (directional lights are not normalised by the shader, inc_structs.glsl:12-16)
-DEV void eval_light(const Px &q, f3 L, f3 rad, f3 &res)
+template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> rad, V3<T> &res)
 {
-    f3 H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
-    float rh = rsq_(dot3(H, H));
-    eval_tail(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), rad, res);
+    V3<T> H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
+    T rh = rsq_(dot3(H, H));
+    eval_tail<T>(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), rad, res);
 }
 // |L| = 1 (point lights, normalised here):  |L+V|^2 = 2 + 2 L.V,  N.H = (N.L + N.V) / |L+V|,  L.H = (1 + L.V) / |L+V|
-DEV void eval_light_unit(const Px &q, f3 L, f3 rad, f3 &res)
+template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> rad, V3<T> &res)
 {
-    float nl = dot3(q.N, L), lv = dot3(L, q.V);
-    float rh = rsq_(__builtin_fmaf(2.0f, lv, 2.0f));
-    eval_tail(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(__builtin_fmaf(lv, rh, rh)), rad, res);
+    T nl = dot3(q.N, L), lv = dot3(L, q.V);
+    T rh = rsq_(fma_((T)2.0f, lv, (T)2.0f));
+    eval_tail<T>(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(fma_(lv, rh, rh)), rad, res);
 }
 
 DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
 {
     f3 rad = { d.b.x, d.b.y, d.b.z };
     if (use_shadow) { rad.x *= shadow; rad.y *= shadow; rad.z *= shadow; }
-    eval_light(q, f3{ d.a.x, d.a.y, d.a.z }, rad, res);
+    eval_light<float>(q, f3{ d.a.x, d.a.y, d.a.z }, rad, res);
+}
+DEV void add_directional2(const Px2 &q, DirRec d, v2f shadow, bool use_shadow, V3<v2f> &res)
+{
+    V3<v2f> rad = { (v2f)(d.b.x), (v2f)(d.b.y), (v2f)(d.b.z) };
+    if (use_shadow) { rad.x *= shadow; rad.y *= shadow; rad.z *= shadow; }
+    eval_light<v2f>(q, V3<v2f>{ (v2f)(d.a.x), (v2f)(d.a.y), (v2f)(d.a.z) }, rad, res);
 }
 
 DEV float point_d2(const Px &q, v4f a, f3 &Lv)
@@ -337,11 +378,11 @@ DEV bool point_test(const Px &q, v4f a, f3 &Lv, float &d2)
 DEV void point_eval(const Px &q, v4f a, v4f b, f3 Lv, float d2, bool on, f3 &res)
 {
     float inv = rsq_(fmaxf(d2, 1e-12f));
-    f3 L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
+    V3<float> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
     float qq = d2 * b.w, w = sat(__builtin_fmaf(-qq, qq, 1.0f));
     float att = on ? (w * w) * rcp_(d2 + 1e-4f) : 0.0f;         // select, not multiply: 0 stays 0 for non-finite BRDF values
-    f3 t = { 0.0f, 0.0f, 0.0f };
-    eval_light_unit(q, L, f3{ b.x * att, b.y * att, b.z * att }, t);
+    V3<float> t = { 0.0f, 0.0f, 0.0f };
+    eval_light_unit<float>(q, L, V3<float>{ b.x * att, b.y * att, b.z * att }, t);
     if (on) { res.x += t.x; res.y += t.y; res.z += t.z; }
 }
 DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
@@ -351,6 +392,25 @@ DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
     const bool on = point_test(q, a, Lv, d2);
     if (__builtin_amdgcn_ballot_w64(on) == 0) return;           // wave-uniform early out
     point_eval(q, a, b, Lv, d2, on, res);
+}
+// two pixels per lane: the same arithmetic per pixel, bit for bit (packed ops round like the scalar ones)
+DEV v2f point_d2_2(const Px2 &q, v4f a, V3<v2f> &Lv)
+{
+    Lv = V3<v2f>{ a.x - q.P.x, a.y - q.P.y, a.z - q.P.z };
+    return fma_(Lv.z, Lv.z, fma_(Lv.y, Lv.y, Lv.x * Lv.x));
+}
+DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1, V3<v2f> &res)
+{
+    v2f inv = rsq_(max_(d2, (v2f)(1e-12f)));
+    V3<v2f> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
+    v2f qq = d2 * b.w, w = sat(fma_(-qq, qq, (v2f)(1.0f)));
+    v2f att = (w * w) * rcp_(d2 + 1e-4f);
+    att = v2f{ on0 ? att.x : 0.0f, on1 ? att.y : 0.0f };
+    V3<v2f> t = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+    eval_light_unit<v2f>(q, L, V3<v2f>{ b.x * att, b.y * att, b.z * att }, t);
+    res.x += v2f{ on0 ? t.x.x : 0.0f, on1 ? t.x.y : 0.0f };
+    res.y += v2f{ on0 ? t.y.x : 0.0f, on1 ? t.y.y : 0.0f };
+    res.z += v2f{ on0 ? t.z.x : 0.0f, on1 ? t.z.y : 0.0f };
 }
 DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t u2, f3 &res)
 {
@@ -618,7 +678,7 @@ DEV v4f bcast4(v4f v, int k)
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
+__global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t lane = threadIdx.x & 63u;
@@ -634,13 +694,16 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
     float *s_res = (float *)(s_wave + L.stash);
     float *s_shadow = (float *)(s_wave + L.shadow);
 
-    // Workgroups keep dispatch (round-robin over XCDs) order: neighbouring tile groups land on
-    // different XCDs, which balances the heavy (many-light) screen regions over the chip.  Giving
-    // each XCD one contiguous run of tiles measured 15 % slower on the headline frame (imbalance),
-    // and nothing is lost: a workgroup already reads whole 256-byte row segments by itself.
+    // Workgroup -> tile: consecutive workgroups (dealt round-robin over the XCDs by the dispatcher) walk along one
+    // tile row; the ROWS are visited in a golden-ratio stride order (row = i * row_mul mod tiles_y, gcd = 1), so
+    // that at any moment the resident waves are a mix of cheap bandwidth-bound rows (sky, far floor) and
+    // VALU-heavy rows (many lights, shadows) instead of one kind at a time, and the tail of the launch is an
+    // average mix, not the most expensive rows of the frame.  Nothing depends on it but speed.
     const uint32_t bpr = (p.tiles_x + wpb - 1) / wpb, blk = blockIdx.x;
-    const uint32_t tyi = blk / bpr, txi = (blk - tyi * bpr) * wpb + wv;
+    const uint32_t ri = blk / bpr, tyi = (p.tune & 1u) ? ri : (uint32_t)(((uint64_t)ri * p.row_mul) % p.tiles_y);
+    const uint32_t txi = (blk - ri * bpr) * wpb + wv;
     if (txi >= p.tiles_x) return;                       // whole wave; nothing below synchronises across waves
+    const uint64_t t_start = p.tile_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
 
     // ---- 1. HBM -> LDS, coordinates clamped (not branched) so the loads are straight-line ----
     const uint32_t x = txi * TILE + (lane & 15u), y0 = tyi * TILE + (lane >> 4);
@@ -741,13 +804,28 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
         total += cnt;
 
         // ---- 5. lane k <- record of list entry kb + k ----
-        auto gather = [&](uint32_t kb, v4f &ra, v4f &rb) {
+        auto gather = [&](uint32_t kb, v4f &ga, v4f &gb) {
             const uint32_t li = base + s_list[min(kb + lane, cnt - 1)];
-            ra = point_rec_a_v(p, li); rb = point_rec_b_v(p, li);
+            ga = point_rec_a_v(p, li); gb = point_rec_b_v(p, li);
         };
-        v4f ra0 = { 0.0f, 0.0f, 0.0f, 0.0f }, rb0 = ra0;
-        if (cnt) gather(0, ra0, rb0);
+        v4f ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
+        if (cnt) gather(0, ra, rb);       // stays in registers across the passes unless the list is longer than 64
 
+        // E3 shadow term of one pixel (integer logic shared by both numeric modes)
+        auto shadow_px = [&](f3 P) -> float {
+            const ShadowTap st = shadow_tap(P, p);
+            if (!staged) return pcf_direct(st, p);
+            if (!st.inside) return 1.0f;
+            int c9 = 0;
+            const int bx = st.tx - rx0, by = st.ty - ry0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                for (int dx = -1; dx <= 1; dx++) c9 += (st.zc <= s_shadow[(by + dy) * rw + bx + dx]) ? 1 : 0;
+            return pcf_result(c9);
+        };
+
+#if MIL_STRICT
         // ---- 6. four passes of 64 pixels ----
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; j++) {
@@ -755,42 +833,17 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
             const uint32_t u1 = s_tex[(0 + j) * 64 + lane], w2 = s_tex[(4 + j) * 64 + lane], u3 = s_tex[(8 + j) * 64 + lane];
             const float depth = __uint_as_float(s_tex[(12 + j) * 64 + lane]);
             const bool inbj = xin && y <= ylast, litj = inbj && (w2 >> 24) != 0;
-#if !MIL_STRICT
-            // occlusion 0 (cleared G-buffer, render/mod.rs:129-131: sky / background) multiplies every term of
-            // fs_deferred_lighting.glsl:63 and of the extensions: the pixel is exactly 0.  When none of the
-            // pass's 64 pixels is lit the wave writes the zeros and skips the shading altogether.
-            if (__builtin_amdgcn_ballot_w64(litj) == 0) {
-                if (ch + 1 == n_chunks && inbj) store_pixel<FMT>(p, x, y, f3{ 0.0f, 0.0f, 0.0f });
-                continue;
-            }
-#endif
             Px q;
             setup_pixel(q, p, pixel_position(p, x, y, depth), u1, w2, u3);
             f3 r = { 0.0f, 0.0f, 0.0f };
             if (ch == 0) {
                 float shadow = 1.0f;
-                if (do_shadow && litj) {
-                    const ShadowTap st = shadow_tap(q.P, p);
-                    if (staged) {
-                        if (st.inside) {
-                            int c9 = 0;
-                            const int bx = st.tx - rx0, by = st.ty - ry0;
-#pragma unroll
-                            for (int dy = -1; dy <= 1; dy++)
-#pragma unroll
-                                for (int dx = -1; dx <= 1; dx++) c9 += (st.zc <= s_shadow[(by + dy) * rw + bx + dx]) ? 1 : 0;
-                            shadow = pcf_result(c9);
-                        }
-                    } else {
-                        shadow = pcf_direct(st, p);
-                    }
-                }
+                if (do_shadow && litj) shadow = shadow_px(q.P);
                 for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
             } else {
                 r = f3{ s_res[j * 64 + lane], s_res[256 + j * 64 + lane], s_res[512 + j * 64 + lane] };
             }
             if (cnt) {
-                v4f ra = ra0, rb = rb0;
                 uint32_t kb = 0;
 #pragma unroll 1
                 for (;;) {
@@ -808,6 +861,7 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
                     if (kb >= cnt) break;
                     gather(kb, ra, rb);
                 }
+                if (cnt > 64 && j < 3) gather(0, ra, rb);
             }
             if (ch + 1 == n_chunks) {
                 if (p.has_ambient) add_ambient(q, p, w2, r);
@@ -816,9 +870,87 @@ __global__ __launch_bounds__(256) void k_tiled(const ShadeParams p)
                 s_res[j * 64 + lane] = r.x; s_res[256 + j * 64 + lane] = r.y; s_res[512 + j * 64 + lane] = r.z;
             }
         }
+#else
+        // ---- 6. two passes of 128 pixels: each lane shades rows ja and ja + 1 of its column together (v2f) ----
+#pragma unroll 1
+        for (uint32_t jp = 0; jp < 2; jp++) {
+            const uint32_t ja = 2 * jp, ya = y0 + 4 * ja, yb = ya + 4;
+            const v2u u1 = { s_tex[(0 + ja) * 64 + lane], s_tex[(1 + ja) * 64 + lane] };
+            const v2u w2 = { s_tex[(4 + ja) * 64 + lane], s_tex[(5 + ja) * 64 + lane] };
+            const v2u u3 = { s_tex[(8 + ja) * 64 + lane], s_tex[(9 + ja) * 64 + lane] };
+            const v2f depth = { __uint_as_float(s_tex[(12 + ja) * 64 + lane]), __uint_as_float(s_tex[(13 + ja) * 64 + lane]) };
+            const bool inA = xin && ya <= ylast, inB = xin && yb <= ylast;
+            const bool litA = inA && (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
+            const bool last = ch + 1 == n_chunks;
+            // occlusion 0 (cleared G-buffer, render/mod.rs:129-131: sky / background) multiplies every term of
+            // fs_deferred_lighting.glsl:63 and of the extensions: the pixel is exactly 0.  When none of the
+            // pass's 128 pixels is lit the wave writes the zeros and skips the shading altogether.
+            if (__builtin_amdgcn_ballot_w64(litA || litB) == 0) {
+                if (last && inA) store_pixel<FMT>(p, x, ya, f3{ 0.0f, 0.0f, 0.0f });
+                if (last && inB) store_pixel<FMT>(p, x, yb, f3{ 0.0f, 0.0f, 0.0f });
+                continue;
+            }
+            Px2 q;
+            setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + p.y_offset), (float)(yb + p.y_offset) }, depth),
+                                    u1, w2, u3);
+            V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+            if (ch == 0) {
+                v2f shadow = { 1.0f, 1.0f };
+                if (do_shadow) {
+                    if (litA) shadow.x = shadow_px(f3{ q.P.x.x, q.P.y.x, q.P.z.x });
+                    if (litB) shadow.y = shadow_px(f3{ q.P.x.y, q.P.y.y, q.P.z.y });
+                }
+                for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
+            } else {
+                r.x = v2f{ s_res[ja * 64 + lane], s_res[(ja + 1) * 64 + lane] };
+                r.y = v2f{ s_res[256 + ja * 64 + lane], s_res[256 + (ja + 1) * 64 + lane] };
+                r.z = v2f{ s_res[512 + ja * 64 + lane], s_res[512 + (ja + 1) * 64 + lane] };
+            }
+            if (cnt) {
+                uint32_t kb = 0;
+#pragma unroll 1
+                for (;;) {
+                    const uint32_t n = min(64u, cnt - kb);
+#pragma unroll 1
+                    for (uint32_t k = 0; k < n; k++) {
+                        const v4f a = bcast4(ra, (int)k);
+                        V3<v2f> Lv;
+                        const v2f d2 = point_d2_2(q, a, Lv);
+                        const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
+                        if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;   // wave-uniform: nobody in range
+                        point_eval2(q, bcast4(rb, (int)k), Lv, d2, on0, on1, r);
+                    }
+                    kb += 64;
+                    if (kb >= cnt) break;
+                    gather(kb, ra, rb);
+                }
+                if (cnt > 64 && jp == 0) gather(0, ra, rb);
+            }
+            if (last) {
+                if (p.has_ambient) {
+                    const v2f ka = q.occ * (1.0f / 255.0f);       // albedo * occlusion re-decoded from the texel
+                    r.x = fma_((v2f)(p.ambient[0]), tof(w2 & 0xFFu) * ka, r.x);
+                    r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
+                    r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
+                }
+                if (inA) store_pixel<FMT>(p, x, ya, f3{ r.x.x, r.y.x, r.z.x });
+                if (inB) store_pixel<FMT>(p, x, yb, f3{ r.x.y, r.y.y, r.z.y });
+            } else {
+                s_res[ja * 64 + lane] = r.x.x; s_res[(ja + 1) * 64 + lane] = r.x.y;
+                s_res[256 + ja * 64 + lane] = r.y.x; s_res[256 + (ja + 1) * 64 + lane] = r.y.y;
+                s_res[512 + ja * 64 + lane] = r.z.x; s_res[512 + (ja + 1) * 64 + lane] = r.z.y;
+            }
+        }
+#endif
         __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next chunk only after these reads were issued
     }
     if (p.tile_counts && lane == 0) p.tile_counts[tyi * p.tiles_x + txi] = total;
+    if (p.tile_stamps && lane == 0) {                    // diagnostics: wave lifetime and placement
+        uint32_t *st = p.tile_stamps + 4 * (size_t)(tyi * p.tiles_x + txi);
+        st[0] = (uint32_t)t_start; st[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); st[2] = total;
+        st[3] = (__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11)) & 0xFFFFu) |          // HW_REG_HW_ID[15:0]
+                (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16);             // HW_REG_XCC_ID[3:0]
+    }
 }
 
 // ---------------------------------------------------------------------------------

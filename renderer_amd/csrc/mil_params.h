@@ -29,7 +29,7 @@ struct ShadeParams {
     const float4 *point_prep; // {position.xyz, radius^2} {color.xyz * intensity, 1/r^2}   (fast)
     const float4 *point_cull; // {position.xyz, radius}, 16 bytes per light                 (tile culling, both modes)
     uint32_t rows_per_block;  // K1: pixels per lane (1 or 4; tuning)
-    uint32_t tune;            // experiment bits (env MIL_TUNE): 1 = no XCD remap in K2
+    uint32_t tune;            // experiment bits (env MIL_TUNE): 1 = K2 tile rows in plain order, 2/4 = 1/2 waves per workgroup
     float ambient[3];
     uint32_t has_ambient;
     // shadow extension
@@ -41,7 +41,9 @@ struct ShadeParams {
     void *out;
     uint32_t out_pitch;
     uint32_t tiles_x, tiles_y;
+    uint32_t row_mul;           // K2 visits tile rows in the order i * row_mul mod tiles_y (coprime)
     uint32_t *tile_counts;      // optional per-tile list length (diagnostics)
+    uint32_t *tile_stamps;      // optional 4 x u32 per tile: start, end (100 MHz ticks), list length, HW_ID (diagnostics)
     const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
 };
 

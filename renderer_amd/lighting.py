@@ -23,7 +23,7 @@ FLAG_STRICT, FLAG_NO_CULL, FLAG_SHADOW_LDS = 1, 2, 4
 TILE = 16
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
-           'mil_set_tile_count_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
+           'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
            'mil_light_ex', 'mil_count_pairs']
 
 
@@ -70,6 +70,7 @@ def load_library(path=LIB_PATH):
         lib.mil_destroy.restype = None
         lib.mil_last_hip_error.argtypes = [ctypes.c_void_p]
         lib.mil_set_tile_count_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.mil_set_tile_stamp_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.mil_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         vp, u32 = ctypes.c_void_p, ctypes.c_uint32
         lib.mil_light_directional.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, vp, u32, u32, vp]
@@ -204,6 +205,14 @@ class LightingPass:
         h, w = gb['depth'].shape
         buf = t.zeros(((h + TILE - 1) // TILE, (w + TILE - 1) // TILE), dtype=t.int32, device=self.device)
         self._check(self.lib.mil_set_tile_count_buffer(self.ctx, buf.data_ptr() if enable else None))
+        return buf
+
+    def tile_stamps(self, gb, enable=True):
+        """Diagnostics: (tiles_y, tiles_x, 4) int32 the next culled call fills with start, end (100 MHz), count, HW_ID."""
+        t = self.torch
+        h, w = gb['depth'].shape
+        buf = t.zeros(((h + TILE - 1) // TILE, (w + TILE - 1) // TILE, 4), dtype=t.int32, device=self.device)
+        self._check(self.lib.mil_set_tile_stamp_buffer(self.ctx, buf.data_ptr() if enable else None))
         return buf
 
     def sync(self, stream=None):
