@@ -207,13 +207,46 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
     }
     p.tiles_x = (gb->width + MIL_TILE - 1) / MIL_TILE;
     p.tiles_y = (gb->height + MIL_TILE - 1) / MIL_TILE;
-    {   // golden-ratio row stride, made coprime with the row count
-        auto gcd = [](uint32_t a, uint32_t b) { while (b) { uint32_t t = a % b; a = b; b = t; } return a; };
-        uint32_t m = (uint32_t)(0.6180339887 * p.tiles_y + 0.5);
-        if (m < 1) m = 1;
-        while (gcd(m, p.tiles_y) != 1) m++;
-        p.row_mul = m % p.tiles_y ? m % p.tiles_y : 1;
+    for (uint32_t i = 0; i < MIL_MAX_ROW_ORDER; i++) p.row_order[i] = (uint16_t)i;
+}
+
+// Scheduling heuristic of the tiled kernel (speed only; any permutation is correct): tile rows are launched
+// in descending order of the number of point lights whose bounding sphere can project onto them, ties from the
+// bottom of the frame upwards, so that the expensive rows are in flight early and the launch ends on cheap ones.
+void order_rows(mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_point_light *pl, uint32_t n_point)
+{
+    const uint32_t R = p.tiles_y;
+    if (R > MIL_MAX_ROW_ORDER) return;
+    uint32_t w[MIL_MAX_ROW_ORDER];
+    for (uint32_t i = 0; i < R; i++) w[i] = 0;
+    const float *V = f->view, *P = f->projection;      // column-major
+    for (uint32_t i = 0; i < n_point; i++) {
+        const float *c = pl[i].position;
+        const float r = pl[i].radius;
+        const double vy = (double)V[1] * c[0] + (double)V[5] * c[1] + (double)V[9] * c[2] + V[13];
+        const double vz = (double)V[2] * c[0] + (double)V[6] * c[1] + (double)V[10] * c[2] + V[14];
+        const double vw = (double)V[3] * c[0] + (double)V[7] * c[1] + (double)V[11] * c[2] + V[15];
+        double lo = -1.0, hi = 1.0;                     // NDC y range; whole frame unless the sphere is safely in front
+        const double wn = -(vz + r) * (double)P[11] + vw * P[15], wf = -(vz - r) * (double)P[11] + vw * P[15];   // clip w at the sphere's near / far side (P[11] = -1 for a perspective)
+        if (P[11] != 0.0f && wn > 1e-6 && wf > 1e-6 && !(r < 0.0f)) {
+            const double a = (double)P[5] * (vy - r) + (double)P[13] * vw, b = (double)P[5] * (vy + r) + (double)P[13] * vw;
+            const double c0 = a / wn, c1 = a / wf, c2 = b / wn, c3 = b / wf;
+            lo = c0; hi = c0;
+            for (double v : { c1, c2, c3 }) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+        }
+        if (!(lo == lo) || !(hi == hi)) { lo = -1.0; hi = 1.0; }
+        double y0 = (lo * 0.5 + 0.5) * p.res_y - (double)p.y_offset, y1 = (hi * 0.5 + 0.5) * p.res_y - (double)p.y_offset;
+        if (y1 < 0.0 || y0 >= (double)p.height) continue;
+        const uint32_t r0 = y0 <= 0.0 ? 0u : (uint32_t)(y0 / MIL_TILE), r1 = y1 >= (double)p.height ? R - 1 : (uint32_t)(y1 / MIL_TILE);
+        for (uint32_t k = r0; k <= r1 && k < R; k++) w[k]++;
     }
+    // stable counting order: weight descending, then row index descending (bottom first)
+    uint32_t n = 0;
+    uint32_t wmax = 0;
+    for (uint32_t i = 0; i < R; i++) wmax = w[i] > wmax ? w[i] : wmax;
+    for (uint32_t lvl = wmax + 1; lvl-- > 0;)
+        for (uint32_t i = R; i-- > 0;)
+            if (w[i] == lvl) p.row_order[n++] = (uint16_t)i;
 }
 
 int finish(mil_ctx *c, Slot *sl, hipStream_t s)
@@ -373,6 +406,7 @@ int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     const bool strict = (flags & MIL_FLAG_STRICT) != 0;
     const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
     if (tiled) {
+        order_rows(p, frame, ex ? ex->point_lights : nullptr, n_point);
         p.tile_counts = c->tile_counts;
         p.tile_stamps = c->tile_stamps;
         if (strict) mil::strict::launch_tiled((int)fmt, p, s);

@@ -677,9 +677,21 @@ DEV v4f bcast4(v4f v, int k)
     return v4f{ lane_f(v.x, k), lane_f(v.y, k), lane_f(v.z, k), lane_f(v.w, k) };
 }
 
-template <int FMT>
-__global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p)
+// The kernel-argument block again, through a pointer the optimiser cannot see through: uniforms read
+// through it are re-fetched from the scalar cache in the phase that uses them instead of being held in
+// SGPRs across the whole kernel (which spills them into VGPR lanes).
+typedef const __attribute__((address_space(4))) ShadeParams *kparams_t;
+DEV const ShadeParams &kernarg_params()
 {
+    kparams_t pp = (kparams_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(pp));
+    return *(const ShadeParams *)pp;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
+{
+    const ShadeParams &p = kernarg_params();
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -695,12 +707,11 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p)
     float *s_shadow = (float *)(s_wave + L.shadow);
 
     // Workgroup -> tile: consecutive workgroups (dealt round-robin over the XCDs by the dispatcher) walk along one
-    // tile row; the ROWS are visited in a golden-ratio stride order (row = i * row_mul mod tiles_y, gcd = 1), so
-    // that at any moment the resident waves are a mix of cheap bandwidth-bound rows (sky, far floor) and
-    // VALU-heavy rows (many lights, shadows) instead of one kind at a time, and the tail of the launch is an
-    // average mix, not the most expensive rows of the frame.  Nothing depends on it but speed.
+    // tile row (a workgroup reads whole 256-byte row segments).  The ROWS are visited in the order the host
+    // computed (mil_api.cpp order_rows): rows that many point lights reach first, cheap rows last, so the
+    // expensive waves are not the tail of the launch.  Nothing depends on the order but speed.
     const uint32_t bpr = (p.tiles_x + wpb - 1) / wpb, blk = blockIdx.x;
-    const uint32_t ri = blk / bpr, tyi = (p.tune & 1u) ? ri : (uint32_t)(((uint64_t)ri * p.row_mul) % p.tiles_y);
+    const uint32_t ri = blk / bpr, tyi = (p.tune & 1u) || p.tiles_y > MIL_MAX_ROW_ORDER ? ri : (uint32_t)p.row_order[ri];
     const uint32_t txi = (blk - ri * bpr) * wpb + wv;
     if (txi >= p.tiles_x) return;                       // whole wave; nothing below synchronises across waves
     const uint64_t t_start = p.tile_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
@@ -829,6 +840,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p)
         // ---- 6. four passes of 64 pixels ----
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; j++) {
+            const ShadeParams &p = kernarg_params();
             const uint32_t y = y0 + 4 * j;
             const uint32_t u1 = s_tex[(0 + j) * 64 + lane], w2 = s_tex[(4 + j) * 64 + lane], u3 = s_tex[(8 + j) * 64 + lane];
             const float depth = __uint_as_float(s_tex[(12 + j) * 64 + lane]);
@@ -874,6 +886,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p)
         // ---- 6. two passes of 128 pixels: each lane shades rows ja and ja + 1 of its column together (v2f) ----
 #pragma unroll 1
         for (uint32_t jp = 0; jp < 2; jp++) {
+            const ShadeParams &p = kernarg_params();
             const uint32_t ja = 2 * jp, ya = y0 + 4 * ja, yb = ya + 4;
             const v2u u1 = { s_tex[(0 + ja) * 64 + lane], s_tex[(1 + ja) * 64 + lane] };
             const v2u w2 = { s_tex[(4 + ja) * 64 + lane], s_tex[(5 + ja) * 64 + lane] };

@@ -9,6 +9,7 @@
 namespace mil {
 
 #define MIL_DIR_INLINE 4u
+#define MIL_MAX_ROW_ORDER 288u   // tile rows of a 4608-row frame; taller frames use plain order
 
 struct ShadeParams {
     // G-buffer planes (device), see mil_gbuffer
@@ -41,7 +42,7 @@ struct ShadeParams {
     void *out;
     uint32_t out_pitch;
     uint32_t tiles_x, tiles_y;
-    uint32_t row_mul;           // K2 visits tile rows in the order i * row_mul mod tiles_y (coprime)
+    uint16_t row_order[MIL_MAX_ROW_ORDER]; // K2 visits tile row row_order[i] i-th (a permutation; host heuristic, speed only)
     uint32_t *tile_counts;      // optional per-tile list length (diagnostics)
     uint32_t *tile_stamps;      // optional 4 x u32 per tile: start, end (100 MHz ticks), list length, HW_ID (diagnostics)
     const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
