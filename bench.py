@@ -257,7 +257,7 @@ def main():
     valu = aflops / (light_ms * 1e-3) / 1e12
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    kname = 'k_tiled' if (inp['n_point'] or inp['shadow_size']) else 'k_stream'
+    kname = 'k_tiled' if (inp['n_point'] or (inp['shadow_size'] and args.flags & 4)) else 'k_stream'
     if os.path.exists(tpath):
         t = json.load(open(tpath)).get(f'{args.workload}{"_fused" if args.fused else ""}:{kname}')
         if t:

@@ -566,6 +566,14 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
         const float depth = __builtin_nontemporal_load(p.depth + i);
         const DirRec d0 = dir_rec(p, 0);
         if (x >= p.width || y > ylast) return;
+#if !MIL_STRICT
+        // extensions on: a wave whose 64 pixels all have occlusion 0 (cleared G-buffer) writes its exact zeros
+        // and skips shadow taps, point lights and BRDF (the same early-out as k_tiled)
+        if (EXT && __builtin_amdgcn_ballot_w64((u2 >> 24) != 0) == 0) {
+            store_pixel<FMT>(p, x, y, f3{ 0.0f, 0.0f, 0.0f });
+            return;
+        }
+#endif
         shade_stream_pixel<FMT, EXT>(p, x, y, u1, u2, u3, depth, d0);
         return;
     }
@@ -742,12 +750,16 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const float INF = __builtin_inff();
     f3 lo = { INF, INF, INF }, hi = { -INF, -INF, -INF };
     int x0 = 0x7FFFFFFF, x1 = -0x7FFFFFFF, yy0 = 0x7FFFFFFF, yy1 = -0x7FFFFFFF;
-    if (p.n_point > 0 || stage) {
+    bool lit4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)   // occlusion 0 => every point-light term is exactly 0
+        lit4[j] = xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
+    // a tile without a lit pixel (sky) has an empty box: no positions, no reductions, no culling
+    if ((p.n_point > 0 || stage) && __builtin_amdgcn_ballot_w64(lit4[0] || lit4[1] || lit4[2] || lit4[3]) != 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t w2 = s_tex[(4 + j) * 64 + lane];
             const f3 P = pixel_position(p, x, y0 + 4 * j, __uint_as_float(s_tex[(12 + j) * 64 + lane])).P;
-            const bool lit = xin && (y0 + 4 * j) <= ylast && (w2 >> 24) != 0;   // occlusion 0 => every point-light term is exactly 0
+            const bool lit = lit4[j];
             if (lit) {
                 lo.x = fminf(lo.x, P.x); lo.y = fminf(lo.y, P.y); lo.z = fminf(lo.z, P.z);
                 hi.x = fmaxf(hi.x, P.x); hi.y = fmaxf(hi.y, P.y); hi.z = fmaxf(hi.z, P.z);
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         }
     }
     bool any_lit = false;
-    if (p.n_point > 0) {
+    if (p.n_point > 0 && __builtin_amdgcn_ballot_w64(lo.x <= hi.x) != 0) {
         lo.x = wave_min(lo.x); lo.y = wave_min(lo.y); lo.z = wave_min(lo.z);
         hi.x = wave_max(hi.x); hi.y = wave_max(hi.y); hi.z = wave_max(hi.z);
         any_lit = lo.x <= hi.x;
