@@ -145,6 +145,14 @@ int mil_light_directional(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_m
 int mil_tonemap(mil_ctx *ctx, const float *hdr, uint32_t hdr_pitch_px, uint32_t width, uint32_t height,
                 uint32_t *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream);
 
+/* NEXT ROW.  Replaces the FXAA draw, render/mod.rs:312-329 + shaders/fs_fxaa.glsl:22-91, sampler
+ * NEAREST / CLAMP_TO_EDGE (render/fxaa/mod.rs:76-88): ldr B10G11R11_UFLOAT_PACK32 -> swapchain B8G8R8A8_SRGB
+ * (render/renderer.rs:78-83).  ldr is the WHOLE frame (width x height; taps reach +-4 rows around a pixel, the
+ * halo a strip-sharded caller must have gathered); rows [row_begin, row_begin + row_count) are written to out,
+ * whose row 0 is row_begin.  Both DEVICE, one u32 per pixel. */
+int mil_fxaa(mil_ctx *ctx, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t width, uint32_t height,
+             uint32_t row_begin, uint32_t row_count, uint32_t *out, uint32_t out_pitch_px, uint32_t flags, void *stream);
+
 /* Lighting with the extensions, optionally fused with the tonemap (valid only when
  * nothing else writes hdr in between, unlike the reference's sky/transparency
  * subpasses, render/pbr/mod.rs:420-434).  `out` is float4 per pixel for

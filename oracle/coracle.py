@@ -82,3 +82,14 @@ def tonemap(hdr, fmt, nthreads=0):
 
 def pack_r11g11b10f(r, g, b):
     return int(lib().milo_pack_r11g11b10f(float(r), float(g), float(b)))
+
+
+def fxaa(ldr, row_begin=0, row_count=None, nthreads=0):
+    """oracle.mil_oracle.fxaa in FP32: (h, w) uint32 R11G11B10F -> (row_count, w) uint32 B8G8R8A8 sRGB."""
+    ldr = np.ascontiguousarray(ldr, np.uint32)
+    h, w = ldr.shape
+    row_count = h - row_begin if row_count is None else row_count
+    out = np.empty((row_count, w), np.uint32)
+    lib().milo_fxaa(_p(ldr, ctypes.c_uint32), ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(row_begin),
+                    ctypes.c_int(row_count), _p(out, ctypes.c_uint32), ctypes.c_int(nthreads))
+    return out

@@ -273,6 +273,67 @@ void milo_tonemap(const float *hdr, int width, int height, int hdr_pitch_px, int
         }
 }
 
+/*
+ * NEXT ROW f-1: FXAA, renderer/shaders/fs_fxaa.glsl:22-91, drawn at render/mod.rs:312-329 from the
+ * ldr attachment (B10G11R11_UFLOAT) to the swapchain image (B8G8R8A8_SRGB, render/renderer.rs:78-83).
+ * Sampler (render/fxaa/mod.rs:76-88): NEAREST, CLAMP_TO_EDGE, normalised coordinates, so
+ *   texture(tex, uv) = texel (clamp(floor(uv.x * W), 0, W-1), clamp(floor(uv.y * H), 0, H-1)).
+ * gl_FragCoord.xy = (x + 0.5, y + 0.5).  GLSL constant expressions (1.0/3.0 - 0.5), (2.0/3.0 - 0.5),
+ * (0.25 * FXAA_REDUCE_MUL) are folded the way glslang does it: in double, then rounded to float.
+ */
+static inline void fxaa_tap(const uint32_t *ldr, int W, int H, int pitch, float u, float v, float *rgb)
+{
+    float fx = floorf(u * (float)W), fy = floorf(v * (float)H);
+    int ix = fx < 0.0f ? 0 : (fx > (float)(W - 1) ? W - 1 : (int)fx);
+    int iy = fy < 0.0f ? 0 : (fy > (float)(H - 1) ? H - 1 : (int)fy);
+    milo_unpack_r11g11b10f(ldr[(size_t)iy * pitch + ix], rgb);
+}
+static inline float fxaa_luma(const float *c) { return (c[0] * 0.299f + c[1] * 0.587f) + c[2] * 0.114f; }
+
+void milo_fxaa(const uint32_t *ldr, int width, int height, int pitch_px, int row_begin, int row_count, uint32_t *out,
+               int nthreads)
+{
+    const float K1 = (float)(1.0 / 3.0 - 0.5), K2 = (float)(2.0 / 3.0 - 0.5), KRED = (float)(0.25 * (1.0 / 8.0));
+    const float REDUCE_MIN = (float)(1.0 / 128.0), SPAN = 8.0f;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int yy = 0; yy < row_count; yy++)
+        for (int x = 0; x < width; x++) {
+            const int y = row_begin + yy;
+            const float ivx = 1.0f / (float)width, ivy = 1.0f / (float)height;      /* :23 inverseVP */
+            const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+            float nw[3], ne[3], sw[3], se[3], m[3], t0[3], t1[3], t2[3], t3[3];
+            fxaa_tap(ldr, width, height, pitch_px, (fx + -1.0f) * ivx, (fy + -1.0f) * ivy, nw);   /* :24-28, :37-41 */
+            fxaa_tap(ldr, width, height, pitch_px, (fx + 1.0f) * ivx, (fy + -1.0f) * ivy, ne);
+            fxaa_tap(ldr, width, height, pitch_px, (fx + -1.0f) * ivx, (fy + 1.0f) * ivy, sw);
+            fxaa_tap(ldr, width, height, pitch_px, (fx + 1.0f) * ivx, (fy + 1.0f) * ivy, se);
+            const float umx = fx * ivx, umy = fy * ivy;
+            fxaa_tap(ldr, width, height, pitch_px, umx, umy, m);
+            const float lNW = fxaa_luma(nw), lNE = fxaa_luma(ne), lSW = fxaa_luma(sw), lSE = fxaa_luma(se), lM = fxaa_luma(m);
+            const float lmin = fminf(lM, fminf(fminf(lNW, lNE), fminf(lSW, lSE)));           /* :49-50 */
+            const float lmax = fmaxf(lM, fmaxf(fmaxf(lNW, lNE), fmaxf(lSW, lSE)));
+            float dx = -((lNW + lNE) - (lSW + lSE)), dy = ((lNW + lSW) - (lNE + lSE));        /* :53-54 */
+            const float reduce = fmaxf((((lNW + lNE) + lSW) + lSE) * KRED, REDUCE_MIN);       /* :56-57 */
+            const float rcpmin = 1.0f / (fminf(fabsf(dx), fabsf(dy)) + reduce);               /* :59 */
+            dx = fminf(SPAN, fmaxf(-SPAN, dx * rcpmin)) * ivx;                                 /* :60-62 */
+            dy = fminf(SPAN, fmaxf(-SPAN, dy * rcpmin)) * ivy;
+            fxaa_tap(ldr, width, height, pitch_px, umx + dx * K1, umy + dy * K1, t0);         /* :64 */
+            fxaa_tap(ldr, width, height, pitch_px, umx + dx * K2, umy + dy * K2, t1);
+            fxaa_tap(ldr, width, height, pitch_px, umx + dx * -0.5f, umy + dy * -0.5f, t2);   /* :65 */
+            fxaa_tap(ldr, width, height, pitch_px, umx + dx * 0.5f, umy + dy * 0.5f, t3);
+            float a[3], b[3];
+            for (int c = 0; c < 3; c++) {
+                a[c] = 0.5f * (t0[c] + t1[c]);
+                b[c] = a[c] * 0.5f + 0.25f * (t2[c] + t3[c]);
+            }
+            const float lB = fxaa_luma(b);
+            const float *o = (lB < lmin || lB > lmax) ? a : b;                                 /* :67-71 */
+            out[(size_t)yy * width + x] = srgb8(o[2]) | (srgb8(o[1]) << 8) | (srgb8(o[0]) << 16) | 0xFF000000u;
+        }
+}
+
 int milo_max_threads(void)
 {
 #ifdef _OPENMP

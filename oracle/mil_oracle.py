@@ -346,3 +346,46 @@ def tonemap(hdr, fmt):
     if fmt == OUT_SRGB8_VIA_LDR:
         return encode_b8g8r8a8_srgb(decode_r11g11b10f(encode_r11g11b10f(ldr)))
     raise ValueError(fmt)
+
+
+# --------------------------------------------------------------------------
+# NEXT ROW f-1: FXAA (renderer/shaders/fs_fxaa.glsl:22-91, drawn at render/mod.rs:312-329;
+# sampler NEAREST + CLAMP_TO_EDGE, render/fxaa/mod.rs:76-88) from the ldr attachment to the
+# B8G8R8A8_SRGB swapchain image (render/renderer.rs:78-83).
+# --------------------------------------------------------------------------
+def fxaa(ldr_u32, row_begin=0, row_count=None, return_float=False):
+    """ldr_u32: (h, w) B10G11R11_UFLOAT codes of the WHOLE frame.  Returns the packed swapchain
+    texels of rows [row_begin, row_begin + row_count), or the float rgb when return_float."""
+    ldr_u32 = np.asarray(ldr_u32, dtype=np.uint32)
+    h, w = ldr_u32.shape
+    row_count = h - row_begin if row_count is None else row_count
+    img = decode_r11g11b10f(ldr_u32)                                   # (h, w, 3) float64
+    f32 = lambda v: np.float64(np.float32(v))
+    inv = np.array([f32(1.0 / f32(w)), f32(1.0 / f32(h))])             # 1.0 / resolution, an FP32 value in the shader
+    ys, xs = np.meshgrid(np.arange(row_begin, row_begin + row_count), np.arange(w), indexing='ij')
+    frag = np.stack([xs + 0.5, ys + 0.5], -1)                          # gl_FragCoord.xy
+
+    def tex(uv):                                                       # nearest, clamp to edge
+        ix = np.clip(np.floor(uv[..., 0] * w), 0, w - 1).astype(np.int64)
+        iy = np.clip(np.floor(uv[..., 1] * h), 0, h - 1).astype(np.int64)
+        return img[iy, ix]
+
+    luma_w = np.array([f32(0.299), f32(0.587), f32(0.114)])
+    luma = lambda c: c @ luma_w
+    nw, ne = tex((frag + [-1.0, -1.0]) * inv), tex((frag + [1.0, -1.0]) * inv)       # :24-28, :37-41
+    sw, se = tex((frag + [-1.0, 1.0]) * inv), tex((frag + [1.0, 1.0]) * inv)
+    um = frag * inv
+    m = tex(um)
+    l_nw, l_ne, l_sw, l_se, l_m = luma(nw), luma(ne), luma(sw), luma(se), luma(m)
+    lmin = np.minimum(l_m, np.minimum(np.minimum(l_nw, l_ne), np.minimum(l_sw, l_se)))  # :49-50
+    lmax = np.maximum(l_m, np.maximum(np.maximum(l_nw, l_ne), np.maximum(l_sw, l_se)))
+    d = np.stack([-((l_nw + l_ne) - (l_sw + l_se)), (l_nw + l_sw) - (l_ne + l_se)], -1)  # :53-54
+    reduce = np.maximum((l_nw + l_ne + l_sw + l_se) * (0.25 * (1.0 / 8.0)), 1.0 / 128.0)  # :56-57
+    rcpmin = 1.0 / (np.minimum(np.abs(d[..., 0]), np.abs(d[..., 1])) + reduce)           # :59
+    d = np.clip(d * rcpmin[..., None], -8.0, 8.0) * inv                                   # :60-62
+    k1, k2 = f32(1.0 / 3.0 - 0.5), f32(2.0 / 3.0 - 0.5)               # glslang folds in double, emits floats
+    a = 0.5 * (tex(um + d * k1) + tex(um + d * k2))                   # :64
+    b = a * 0.5 + 0.25 * (tex(um + d * -0.5) + tex(um + d * 0.5))     # :65
+    l_b = luma(b)
+    rgb = np.where(((l_b < lmin) | (l_b > lmax))[..., None], a, b)    # :67-71
+    return rgb if return_float else encode_b8g8r8a8_srgb(rgb)

@@ -443,6 +443,22 @@ int mil_tonemap(mil_ctx *c, const float *hdr, uint32_t hdr_pitch_px, uint32_t wi
     return finish(c, nullptr, (hipStream_t)stream);
 }
 
+int mil_fxaa(mil_ctx *c, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t width, uint32_t height, uint32_t row_begin,
+             uint32_t row_count, uint32_t *out, uint32_t out_pitch_px, uint32_t flags, void *stream)
+{
+    if (!c || !ldr || !out || width == 0 || height == 0) return MIL_ERR_BAD_ARG;
+    if (ldr_pitch_px < width || out_pitch_px < width) return MIL_ERR_BAD_ARG;
+    if (row_count == 0 || (uint64_t)row_begin + row_count > height) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    mil::FxaaParams p;
+    p.ldr = ldr; p.out = out; p.width = width; p.height = height; p.ldr_pitch = ldr_pitch_px; p.out_pitch = out_pitch_px;
+    p.row_begin = row_begin; p.row_count = row_count;
+    if (flags & MIL_FLAG_STRICT) mil::strict::launch_fxaa(p, (hipStream_t)stream);
+    else mil::fast::launch_fxaa(p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream);
+}
+
 int mil_count_pairs(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_push_constants *push,
                     const mil_point_light *pl, uint32_t n_point, unsigned long long *count, void *stream)
 {

@@ -221,10 +221,12 @@ DEV float aces1(float x)
 {
     return clampf((x * (2.51f * x + 0.03f)) / (x * (2.43f * x + 0.59f) + 0.14f), 0.0f, 1.0f);
 }
-DEV uint32_t srgb8_direct(float c)
+DEV uint32_t srgb8_direct(float cf)   // the OETF in double, as oracle/mil_oracle.c srgb8(): exact up to the rounding of pow()
 {
-    float s = c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f;
-    return (uint32_t)floorf(s * 255.0f + 0.5f);
+    double c = (double)cf;
+    c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+    double s = c <= 0.0031308 ? 12.92 * c : 1.055 * pow(c, 1.0 / 2.4) - 0.055;
+    return (uint32_t)floor(s * 255.0 + 0.5);
 }
 
 #else
@@ -1014,6 +1016,98 @@ __global__ __launch_bounds__(256) void k_count_pairs(const ShadeParams p, unsign
 #endif
 
 // ---------------------------------------------------------------------------------
+// K5 (next row f-1): FXAA, renderer/shaders/fs_fxaa.glsl:22-91 (draw: render/mod.rs:312-329), from
+// the ldr attachment (B10G11R11_UFLOAT) to the swapchain image (B8G8R8A8_SRGB).  Sampler: NEAREST,
+// CLAMP_TO_EDGE (render/fxaa/mod.rs:76-88).  One pixel per lane, block 64 x 4; the nine taps are plain
+// dword loads (neighbouring lanes share lines in L1).  A B10G11R11 channel is a bit-field of an FP16
+// number (same 5-bit exponent and bias, shorter mantissa), so a texel decodes EXACTLY with one shift/mask
+// and one v_cvt_f32_f16 per channel, denormals included.
+// ---------------------------------------------------------------------------------
+DEV f3 fxaa_decode(uint32_t u)
+{
+    typedef _Float16 h1;
+    union { unsigned short s; h1 h; } r, g, b;
+    r.s = (unsigned short)((u & 0x7FFu) << 4);
+    g.s = (unsigned short)((u >> 7) & 0x7FF0u);
+    b.s = (unsigned short)((u >> 17) & 0x7FE0u);
+    return f3{ (float)r.h, (float)g.h, (float)b.h };
+}
+DEV f3 fxaa_texel(const FxaaParams &p, int ix, int iy)
+{
+    ix = min(max(ix, 0), (int)p.width - 1); iy = min(max(iy, 0), (int)p.height - 1);
+    return fxaa_decode(p.ldr[(size_t)iy * p.ldr_pitch + ix]);
+}
+#if MIL_STRICT
+DEV f3 fxaa_tap(const FxaaParams &p, float u, float v)     // texture(tex, uv): floor(uv * size), clamp to edge
+{
+    float fx = floorf(u * (float)p.width), fy = floorf(v * (float)p.height);
+    int ix = fx < 0.0f ? 0 : (fx > (float)(p.width - 1) ? (int)p.width - 1 : (int)fx);
+    int iy = fy < 0.0f ? 0 : (fy > (float)(p.height - 1) ? (int)p.height - 1 : (int)fy);
+    return fxaa_decode(p.ldr[(size_t)iy * p.ldr_pitch + ix]);
+}
+DEV float fxaa_luma(f3 c) { return (c.x * 0.299f + c.y * 0.587f) + c.z * 0.114f; }
+#else
+DEV float fxaa_luma(f3 c) { return __builtin_fmaf(c.z, 0.114f, __builtin_fmaf(c.y, 0.587f, c.x * 0.299f)); }
+#endif
+
+__global__ __launch_bounds__(256) void k_fxaa(const FxaaParams p)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, yy = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.width || yy >= p.row_count) return;
+    const uint32_t y = p.row_begin + yy;
+    const float K1 = (float)(1.0 / 3.0 - 0.5), K2 = (float)(2.0 / 3.0 - 0.5), KRED = 0.03125f, REDUCE_MIN = 0.0078125f, SPAN = 8.0f;
+    f3 a, b;
+    float lmin, lmax;
+#if MIL_STRICT
+    const float ivx = 1.0f / (float)p.width, ivy = 1.0f / (float)p.height;      // fs_fxaa.glsl:23
+    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+    const f3 nw = fxaa_tap(p, (fx + -1.0f) * ivx, (fy + -1.0f) * ivy), ne = fxaa_tap(p, (fx + 1.0f) * ivx, (fy + -1.0f) * ivy);
+    const f3 sw = fxaa_tap(p, (fx + -1.0f) * ivx, (fy + 1.0f) * ivy), se = fxaa_tap(p, (fx + 1.0f) * ivx, (fy + 1.0f) * ivy);
+    const float umx = fx * ivx, umy = fy * ivy;
+    const f3 m = fxaa_tap(p, umx, umy);
+    const float lNW = fxaa_luma(nw), lNE = fxaa_luma(ne), lSW = fxaa_luma(sw), lSE = fxaa_luma(se), lM = fxaa_luma(m);
+    lmin = fminf(lM, fminf(fminf(lNW, lNE), fminf(lSW, lSE)));                   // :49-50
+    lmax = fmaxf(lM, fmaxf(fmaxf(lNW, lNE), fmaxf(lSW, lSE)));
+    float dx = -((lNW + lNE) - (lSW + lSE)), dy = ((lNW + lSW) - (lNE + lSE));    // :53-54
+    const float reduce = fmaxf((((lNW + lNE) + lSW) + lSE) * KRED, REDUCE_MIN);   // :56-57
+    const float rcpmin = 1.0f / (fminf(fabsf(dx), fabsf(dy)) + reduce);           // :59
+    dx = fminf(SPAN, fmaxf(-SPAN, dx * rcpmin)) * ivx;                             // :60-62
+    dy = fminf(SPAN, fmaxf(-SPAN, dy * rcpmin)) * ivy;
+    const f3 t0 = fxaa_tap(p, umx + dx * K1, umy + dy * K1), t1 = fxaa_tap(p, umx + dx * K2, umy + dy * K2);   // :64
+    const f3 t2 = fxaa_tap(p, umx + dx * -0.5f, umy + dy * -0.5f), t3 = fxaa_tap(p, umx + dx * 0.5f, umy + dy * 0.5f);   // :65
+    a = f3{ 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
+    b = f3{ a.x * 0.5f + 0.25f * (t2.x + t3.x), a.y * 0.5f + 0.25f * (t2.y + t3.y), a.z * 0.5f + 0.25f * (t2.z + t3.z) };
+#else
+    // The five fixed taps are the integer neighbours ((x + 0.5 +- 1) / W * W floors to x +- 1); the four
+    // directional taps are formed in pixel units, without the round trip through normalised coordinates.
+    const int xi = (int)x, yi = (int)y;
+    const f3 nw = fxaa_texel(p, xi - 1, yi - 1), ne = fxaa_texel(p, xi + 1, yi - 1);
+    const f3 sw = fxaa_texel(p, xi - 1, yi + 1), se = fxaa_texel(p, xi + 1, yi + 1);
+    const f3 m = fxaa_decode(p.ldr[(size_t)y * p.ldr_pitch + x]);
+    const float lNW = fxaa_luma(nw), lNE = fxaa_luma(ne), lSW = fxaa_luma(sw), lSE = fxaa_luma(se), lM = fxaa_luma(m);
+    lmin = fminf(lM, fminf(fminf(lNW, lNE), fminf(lSW, lSE)));
+    lmax = fmaxf(lM, fmaxf(fmaxf(lNW, lNE), fmaxf(lSW, lSE)));
+    float dx = (lSW + lSE) - (lNW + lNE), dy = (lNW + lSW) - (lNE + lSE);
+    const float reduce = fmaxf((lNW + lNE + lSW + lSE) * KRED, REDUCE_MIN);
+    const float rcpmin = __builtin_amdgcn_rcpf(fminf(fabsf(dx), fabsf(dy)) + reduce);
+    dx = __builtin_amdgcn_fmed3f(dx * rcpmin, -SPAN, SPAN);
+    dy = __builtin_amdgcn_fmed3f(dy * rcpmin, -SPAN, SPAN);
+    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+    auto tap = [&](float k) {
+        return fxaa_texel(p, (int)floorf(__builtin_fmaf(dx, k, fx)), (int)floorf(__builtin_fmaf(dy, k, fy)));
+    };
+    const f3 t0 = tap(K1), t1 = tap(K2), t2 = tap(-0.5f), t3 = tap(0.5f);
+    a = f3{ 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
+    b = f3{ __builtin_fmaf(0.25f, t2.x + t3.x, a.x * 0.5f), __builtin_fmaf(0.25f, t2.y + t3.y, a.y * 0.5f),
+            __builtin_fmaf(0.25f, t2.z + t3.z, a.z * 0.5f) };
+#endif
+    const float lB = fxaa_luma(b);
+    const f3 o = (lB < lmin || lB > lmax) ? a : b;                                 // :67-71
+    __builtin_nontemporal_store(srgb8_direct(sat(o.z)) | (srgb8_direct(sat(o.y)) << 8) | (srgb8_direct(sat(o.x)) << 16) | 0xFF000000u,
+                                p.out + (size_t)yy * p.out_pitch + x);
+}
+
+// ---------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s)
@@ -1054,6 +1148,11 @@ void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
     case FMT_SRGB8: hipLaunchKernelGGL(k_tonemap<FMT_SRGB8>, grid, block, 0, s, p); break;
     default: hipLaunchKernelGGL(k_tonemap<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
     }
+}
+void launch_fxaa(const FxaaParams &p, hipStream_t s)
+{
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.row_count + 3) / 4);
+    hipLaunchKernelGGL(k_fxaa, grid, block, 0, s, p);
 }
 #if !MIL_STRICT
 void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)

@@ -55,17 +55,25 @@ struct TonemapParams {
     const uint8_t *lut11, *lut10;
 };
 
+struct FxaaParams {
+    const uint32_t *ldr;        // whole frame, B10G11R11_UFLOAT_PACK32
+    uint32_t *out;              // rows [row_begin, row_begin + row_count), B8G8R8A8_SRGB
+    uint32_t width, height, ldr_pitch, out_pitch, row_begin, row_count;
+};
+
 // implemented once per numeric mode
 namespace fast {
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
+void launch_fxaa(const FxaaParams &p, hipStream_t s);
 }
 namespace strict {
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
+void launch_fxaa(const FxaaParams &p, hipStream_t s);
 }
 
 } // namespace mil

@@ -24,7 +24,7 @@ TILE = 16
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
-           'mil_light_ex', 'mil_count_pairs']
+           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa']
 
 
 class MilError(RuntimeError):
@@ -77,6 +77,7 @@ def load_library(path=LIB_PATH):
         lib.mil_tonemap.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_int, u32, vp]
         lib.mil_light_ex.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras), vp, u32,
                                      ctypes.c_int, u32, vp]
+        lib.mil_fxaa.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, u32, u32, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
         _lib = lib
     return _lib
@@ -154,6 +155,18 @@ class LightingPass:
             out = t.empty((h, w), dtype=t.int32, device=self.device)
         self._check(self.lib.mil_tonemap(self.ctx, hdr.data_ptr(), hdr.stride(0) // 4, w, h, out.data_ptr(),
                                          out.stride(0), fmt, FLAG_STRICT if strict else 0, self._stream(stream)))
+        return out
+
+    def fxaa(self, ldr, row_begin=0, row_count=None, out=None, strict=False, stream=None):
+        """The FXAA draw (render/mod.rs:312-329): ldr (h, w) int32 R11G11B10F of the whole frame ->
+        (row_count, w) int32 B8G8R8A8 sRGB of rows [row_begin, row_begin + row_count)."""
+        t = self.torch
+        h, w = ldr.shape
+        row_count = h - row_begin if row_count is None else row_count
+        if out is None:
+            out = t.empty((row_count, w), dtype=t.int32, device=self.device)
+        self._check(self.lib.mil_fxaa(self.ctx, ldr.data_ptr(), ldr.stride(0), w, h, row_begin, row_count, out.data_ptr(),
+                                      out.stride(0), FLAG_STRICT if strict else 0, self._stream(stream)))
         return out
 
     def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,

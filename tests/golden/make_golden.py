@@ -4,7 +4,8 @@ vectors for this path and cannot be run here).  Run from the repo 
 Each .npz holds the packed G-buffer planes, uniforms, lights, shadow map and the expected
 outputs: hdr_f64 (float64 NumPy oracle), hdr_c32 / ldr_c32 / srgb8_via_ldr_c32 (FP32 C
 oracle, the bit-exact target of the strict HIP kernels), hdr_dir_only_c32 (reference path
-only: directional lights, no extensions)."""
+only: directional lights, no extensions).  fxaa_101x70.npz: an R11G11B10F frame and its
+FXAA'd B8G8R8A8 sRGB image from both oracles."""
 import os
 import sys
 
@@ -44,4 +45,8 @@ if __name__ == '__main__':
     make('sweep_96x54', synth.to_numpy(synth.scene_sweep(96, 54, cam)), cam)
     cam = synth.sweep_camera(64, 36)
     make('noise_64x36', synth.to_numpy(synth.scene_noise(64, 36, 0x5EED0001)), cam)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from test_oracle_kat import fxaa_test_image
+    ldr = fxaa_test_image(70, 101, 3)
+    np.savez_compressed(os.path.join(OUT, 'fxaa_101x70.npz'), ldr=ldr, srgb8_c32=co.fxaa(ldr), srgb8_f64=mo.fxaa(ldr))
     print('wrote fixtures to', OUT)

@@ -177,7 +177,8 @@ def test_k4_tonemap_strict_bit_exact(lp, coracle):
         out = lp.tonemap(t, fmt, strict=True).cpu().numpy().view(np.uint32)
         np.testing.assert_array_equal(out, coracle.tonemap(hdr, fmt))
     out = lp.tonemap(t, lighting.OUT_SRGB8, strict=True).cpu().numpy().view(np.uint32)
-    assert np.abs(channels(out) - channels(coracle.tonemap(hdr, 2))).max() <= 1     # float powf vs double pow
+    d = np.abs(channels(out) - channels(coracle.tonemap(hdr, 2)))                   # OETF in double on both sides;
+    assert d.max() <= 1 and (d > 0).mean() < 1e-5                                   # only pow()'s last ulp could differ
 
 
 def test_k4_tonemap_fast_tolerance(lp, coracle):
@@ -312,6 +313,61 @@ def test_count_pairs(lp, coracle):
     _, pairs = coracle.shade(*planes_np(gb), frame, dl[:0], point_lights=pl, return_pairs=True)
     got = lp.count_pairs(gb, frame, pl)
     assert abs(got - pairs) <= max(2, 1e-4 * pairs)
+
+
+# ------------------------------------------------------------------ next row f-1: FXAA
+def test_fxaa_strict_bit_exact_and_fast_tolerance(lp, coracle):
+    from test_oracle_kat import fxaa_test_image
+    z = np.load(os.path.join(GOLDEN, 'fxaa_101x70.npz'))
+    for ldr in (z['ldr'], fxaa_test_image(144, 256, 9), fxaa_test_image(33, 65, 1), fxaa_test_image(1, 1), fxaa_test_image(5, 3)):
+        t = torch.from_numpy(ldr.view(np.int32)).to(DEV)
+        ref = coracle.fxaa(ldr)
+        np.testing.assert_array_equal(lp.fxaa(t, strict=True).cpu().numpy().view(np.uint32), ref)   # FP32 in GLSL order: every texel pick identical
+        fast = lp.fxaa(t).cpu().numpy().view(np.uint32)
+        d = np.abs(channels(fast) - channels(mo.fxaa(ldr))).max(-1)
+        assert (d > 1).mean() <= 2e-3                                       # <= 1 LSB; a nearest-texel pick may flip on a boundary
+        assert np.all(channels(fast)[..., 3] == 255)
+    np.testing.assert_array_equal(lp.fxaa(torch.from_numpy(z['ldr'].view(np.int32)).to(DEV), strict=True).cpu().numpy().view(np.uint32),
+                                  z['srgb8_c32'])
+
+
+def test_fxaa_strips_pitch_and_bad_args(lp):
+    from test_oracle_kat import fxaa_test_image
+    ldr = fxaa_test_image(96, 160, 5)
+    t = torch.from_numpy(ldr.view(np.int32)).to(DEV)
+    for strict in (False, True):
+        full = lp.fxaa(t, strict=strict)
+        for y0, n in [(0, 16), (16, 48), (64, 32), (95, 1)]:               # a strip reads its halo from the whole frame
+            assert torch.equal(lp.fxaa(t, y0, n, strict=strict), full[y0:y0 + n])
+        big = torch.zeros((96, 200), dtype=torch.int32, device=DEV)
+        big[:, 7:167] = t
+        outbuf = torch.full((96, 180), -7, dtype=torch.int32, device=DEV)
+        o = lp.fxaa(big[:, 7:167], out=outbuf[:, 3:163], strict=strict)     # pitched input and output
+        assert torch.equal(o, full) and torch.all(outbuf[:, :3] == -7) and torch.all(outbuf[:, 163:] == -7)
+    lib = lp.lib
+    out = torch.empty((96, 160), dtype=torch.int32, device=DEV)
+    assert lib.mil_fxaa(lp.ctx, None, 160, 160, 96, 0, 96, out.data_ptr(), 160, 0, None) == -1
+    assert lib.mil_fxaa(lp.ctx, t.data_ptr(), 100, 160, 96, 0, 96, out.data_ptr(), 160, 0, None) == -1     # pitch < width
+    assert lib.mil_fxaa(lp.ctx, t.data_ptr(), 160, 160, 96, 90, 7, out.data_ptr(), 160, 0, None) == -1      # rows beyond the frame
+    assert lib.mil_fxaa(lp.ctx, t.data_ptr(), 160, 160, 96, 0, 0, out.data_ptr(), 160, 0, None) == -1
+
+
+def test_full_chain_4k_gbuffer_to_swapchain(lp):
+    """G-buffer -> lighting -> tonemap (R11G11B10F) -> FXAA -> B8G8R8A8 sRGB at 3840x2160, against the oracle
+    chain on a 48-row band (the band plus its 4-row FXAA halo is shaded by the oracle)."""
+    w, h = 3840, 2160
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=256, shadow=2048)
+    hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    ldr = lp.tonemap(hdr, lighting.OUT_LDR)
+    img = lp.fxaa(ldr)
+    assert torch.all((img >> 24) & 0xFF == 255)
+    y0, y1 = 992, 1040
+    # the oracle treats the band (+- 8 halo rows) as its whole frame: the taps move by the same pixel offsets
+    # (dir * inverseVP * size), so the texel picks agree up to FP rounding on a boundary
+    ldr_band = ldr[y0 - 8:y1 + 8].cpu().numpy().view(np.uint32)
+    ref = mo.fxaa(ldr_band, 8, y1 - y0)
+    d = np.abs(channels(img[y0:y1].cpu().numpy().view(np.uint32)) - channels(ref)).max(-1)
+    assert (d > 1).mean() <= 5e-3
 
 
 # ------------------------------------------------------------------ full-size properties (BASELINE.json sizes)

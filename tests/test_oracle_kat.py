@@ -219,3 +219,78 @@ def test_golden_fixtures(coracle, name):
     np.testing.assert_array_equal(coracle.tonemap(z['hdr_c32'], 3), z['srgb8_via_ldr_c32'])
     b0 = coracle.shade(*planes, z['frame'], z['dir_lights'])
     np.testing.assert_array_equal(b0.view(np.uint32), z['hdr_dir_only_c32'].view(np.uint32))
+
+
+# ------------------------------------------------------------------ next row f-1: FXAA (fs_fxaa.glsl:22-91)
+def _gray(v):
+    return [v, v, v]
+
+
+def _ch(u):
+    return np.stack([(u >> s) & 0xFF for s in (0, 8, 16, 24)], -1).astype(int)
+
+
+def test_kat8_fxaa_hand_derived(coracle):
+    """3x3 gray frame, centre pixel M = 0 with NW .5, NE .25, SW = SE = 0, W .25, E .5 (all exact in B10G11R11):
+    dir = (-(NW+NE), NW-NE) = (-.75, .25); dirReduce = max(.75 * .03125, 1/128) = .0234375;
+    rcpDirMin = 1 / (.25 + .0234375) = 3.657143; dir * rcpDirMin = (-2.742857, .914286), inside +-8.
+    Taps (pixel units from (1.5, 1.5)): *(-1/6) -> (1.957, 1.348) = M, *(1/6) -> (1.043, 1.652) = M,
+    *(-.5) -> (2.871, 1.043) = E, *(.5) -> (0.129, 1.957) = W.  rgbA = 0, rgbB = 0 * .5 + .25 * (.5 + .25) = .1875,
+    lumaB = .1875 in [0, .5] -> rgbB.  sRGB: 1.055 * .1875^(1/2.4) - .055 = .47021 -> round(119.90) = 120 = 0x78."""
+    img = np.array([[_gray(.5), _gray(.125), _gray(.25)], [_gray(.25), _gray(0), _gray(.5)], [_gray(0), _gray(.125), _gray(0)]])
+    ldr = mo.encode_r11g11b10f(img)
+    assert mo.fxaa(ldr)[1, 1] == 0xFF787878
+    assert coracle.fxaa(ldr)[1, 1] == 0xFF787878
+    np.testing.assert_allclose(mo.fxaa(ldr, return_float=True)[1, 1], 0.1875, rtol=0, atol=1e-12)
+
+
+def test_fxaa_flat_and_axis_aligned_edges_are_untouched(coracle):
+    flat = mo.encode_r11g11b10f(np.full((9, 11, 3), 0.25))
+    plain = lambda ldr: mo.encode_b8g8r8a8_srgb(mo.decode_r11g11b10f(ldr))
+    for f in (mo.fxaa, coracle.fxaa):
+        np.testing.assert_array_equal(f(flat), plain(flat))
+    img = np.zeros((12, 16, 3))
+    img[:, 8:] = 0.75                                   # vertical edge: dir = (0, -8 px): taps stay in the column
+    v = mo.encode_r11g11b10f(img)
+    h = mo.encode_r11g11b10f(img.transpose(1, 0, 2).copy())
+    for f in (mo.fxaa, coracle.fxaa):
+        np.testing.assert_array_equal(f(v), plain(v))
+        np.testing.assert_array_equal(f(h), plain(h))
+
+
+def fxaa_test_image(h, w, seed=0):
+    """Tonemapped-looking frame with diagonal edges, thin lines, noise and dark (denormal) values."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 3))
+    img[..., 0] = (xx * 0.37 + yy * 0.61 > 0.45 * (w + h) / 2) * 0.8 + 0.05
+    img[..., 1] = ((xx + 2 * yy) % 23 < 9) * 0.6 + 0.02 * rng.rand(h, w)
+    img[..., 2] = rng.rand(h, w) ** 3
+    img[: h // 8] *= 1e-4                                # B10G11R11 denormals
+    img[(xx - w // 2) ** 2 + (yy - h // 2) ** 2 < (h // 4) ** 2] = (0.9, 0.85, 0.1)
+    return mo.encode_r11g11b10f(img)
+
+
+def test_fxaa_two_restatements_agree_and_strips(coracle):
+    ldr = fxaa_test_image(70, 101, 3)
+    a, b = mo.fxaa(ldr), coracle.fxaa(ldr)
+    d = np.abs(_ch(a) - _ch(b)).max(-1)
+    assert (d > 1).mean() <= 2e-3 and (d > 0).mean() <= 2e-2      # FP64 vs FP32: rare nearest-texel flips, else <= 1 LSB
+    assert np.all(_ch(b)[..., 3] == 255)
+    for f in (mo.fxaa, coracle.fxaa):                              # rows [y0, y1) of the whole frame == a strip call
+        full = f(ldr)
+        np.testing.assert_array_equal(f(ldr, 16, 32), full[16:48])
+        np.testing.assert_array_equal(f(ldr, 69, 1), full[69:])
+    # every output channel lies within the range of the 9x9 neighbourhood the taps can reach (blend of texels)
+    lin = mo.fxaa(ldr, return_float=True)
+    img = mo.decode_r11g11b10f(ldr)
+    pad = np.pad(img, ((4, 4), (4, 4), (0, 0)), mode='edge')
+    win = np.lib.stride_tricks.sliding_window_view(pad, (9, 9), axis=(0, 1))
+    assert np.all(lin <= win.max((-1, -2)) + 1e-12) and np.all(lin >= win.min((-1, -2)) - 1e-12)
+
+
+def test_fxaa_golden_fixture(coracle):
+    z = np.load(os.path.join(GOLDEN, 'fxaa_101x70.npz'))
+    np.testing.assert_array_equal(coracle.fxaa(z['ldr']), z['srgb8_c32'])
+    d = np.abs(_ch(mo.fxaa(z['ldr'])) - _ch(z['srgb8_f64'])).max()
+    assert d == 0
