@@ -1092,14 +1092,20 @@ __global__ __launch_bounds__(256) void k_fxaa(const FxaaParams p)
     const float rcpmin = __builtin_amdgcn_rcpf(fminf(fabsf(dx), fabsf(dy)) + reduce);
     dx = __builtin_amdgcn_fmed3f(dx * rcpmin, -SPAN, SPAN);
     dy = __builtin_amdgcn_fmed3f(dy * rcpmin, -SPAN, SPAN);
-    const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
-    auto tap = [&](float k) {
-        return fxaa_texel(p, (int)floorf(__builtin_fmaf(dx, k, fx)), (int)floorf(__builtin_fmaf(dy, k, fy)));
-    };
-    const f3 t0 = tap(K1), t1 = tap(K2), t2 = tap(-0.5f), t3 = tap(0.5f);
-    a = f3{ 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
-    b = f3{ __builtin_fmaf(0.25f, t2.x + t3.x, a.x * 0.5f), __builtin_fmaf(0.25f, t2.y + t3.y, a.y * 0.5f),
-            __builtin_fmaf(0.25f, t2.z + t3.z, a.z * 0.5f) };
+    a = m; b = m;
+    // |dir| < 1 pixel: the four taps at dir * {-1/2, -1/6, 1/6, 1/2} all stay inside the centre texel, so
+    // rgbA = rgbB = M exactly (0.5 M + 0.25 (M + M)).  Smooth regions are most of a frame: when it holds for
+    // the whole wave the taps and the blend are skipped.
+    if (__builtin_amdgcn_ballot_w64(fmaxf(fabsf(dx), fabsf(dy)) > 0.99f) != 0) {
+        const float fx = (float)x + 0.5f, fy = (float)y + 0.5f;
+        auto tap = [&](float k) {
+            return fxaa_texel(p, (int)floorf(__builtin_fmaf(dx, k, fx)), (int)floorf(__builtin_fmaf(dy, k, fy)));
+        };
+        const f3 t0 = tap(K1), t1 = tap(K2), t2 = tap(-0.5f), t3 = tap(0.5f);
+        a = f3{ 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
+        b = f3{ __builtin_fmaf(0.25f, t2.x + t3.x, a.x * 0.5f), __builtin_fmaf(0.25f, t2.y + t3.y, a.y * 0.5f),
+                __builtin_fmaf(0.25f, t2.z + t3.z, a.z * 0.5f) };
+    }
 #endif
     const float lB = fxaa_luma(b);
     const f3 o = (lB < lmin || lB > lmax) ? a : b;                                 // :67-71

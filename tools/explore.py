@@ -59,6 +59,15 @@ def tm(fmt):
     return f
 if not os.environ.get('K1ONLY') and not os.environ.get('HLONLY'):
   for fmt in (1, 2, 3): print(f'tonemap fmt {fmt:38d} {timeit(tm(fmt)):9.1f} us')
+ldrs = [lp.tonemap(hdrs[i], 1) for i in range(3)]
+def fx(strict=False):
+    def f():
+        i = it[0] % 3; it[0] += 1
+        lp.fxaa(ldrs[i], out=outs[i], strict=strict)
+    return f
+if not os.environ.get('K1ONLY') and not os.environ.get('HLONLY'):
+    print(f'{"fxaa R11G11B10F -> sRGB8":50s} {timeit(fx()):9.1f} us')
+    print(f'{"fxaa strict":50s} {timeit(fx(True)):9.1f} us')
 # memcpy reference: copy 16 B/px in, 16 B/px out
 if os.environ.get('K1ONLY') or os.environ.get('HLONLY'): sys.exit(0)
 a = torch.empty(W * H * 4, device=dev); b = torch.empty_like(a)
