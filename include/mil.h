@@ -153,6 +153,30 @@ int mil_tonemap(mil_ctx *ctx, const float *hdr, uint32_t hdr_pitch_px, uint32_t 
 int mil_fxaa(mil_ctx *ctx, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t width, uint32_t height,
              uint32_t row_begin, uint32_t row_count, uint32_t *out, uint32_t out_pitch_px, uint32_t flags, void *stream);
 
+/* HosekWilkieParams - render/hosek/mod.rs:222-256; GLSL block shaders/sky_hosek_frag.glsl:14-26.  std140, 176 bytes:
+ * eleven vec3 at 16-byte stride, filled on the CPU by make_hosek_wilkie_params (hosek/mod.rs:181-220, from the
+ * model's dataset: NOT part of this library; the caller passes the block it already builds per frame). */
+typedef struct mil_hosek_wilkie_params {
+    float a[3], _p0, b[3], _p1, c[3], _p2, d[3], _p3, e[3], _p4, f[3], _p5, g[3], _p6, h[3], _p7, i[3], _p8, z[3], _p9;
+    float sun_direction[3], _p10;
+} mil_hosek_wilkie_params;
+
+/* NEXT ROW.  Replaces the sky draw, render/mod.rs:221-226 + shaders/sky_hosek_vert.glsl,
+ * sky_hosek_frag.glsl:28-60, as a screen-space pass: every texel still at the clear depth (the draw's LessOrEqual
+ * test at z = w - 1e-5, render/hosek/mod.rs:58-64) gets hdr = (radiance * 0.05, 1); the others keep hdr.
+ * depth, hdr: DEVICE (strip: y_offset as in mil_gbuffer; push->resolution = full frame). */
+int mil_sky_hosek(mil_ctx *ctx, const float *depth, uint32_t depth_pitch_px, uint32_t width, uint32_t height,
+                  uint32_t y_offset, const mil_frame_matrix_data *frame, const mil_push_constants *push,
+                  const mil_hosek_wilkie_params *params, float *hdr, uint32_t hdr_pitch_px, uint32_t flags, void *stream);
+
+/* NEXT ROW.  Replaces the transparency resolve draw, render/mod.rs:282-294 +
+ * shaders/fs_mcguire13_resolve.glsl:8-13 with the blend state of render/mcguire13/mod.rs:108-120:
+ * hdr = (accum.rgb / clamp(accum.a, 1e-4, 5e4), reveal) * (1 - reveal) + hdr * reveal.
+ * accum: DEVICE R16G16B16A16_SFLOAT, reveal: DEVICE R16_SFLOAT (mcguire13/mod.rs:22-23), hdr: DEVICE, in/out. */
+int mil_transparency_resolve(mil_ctx *ctx, const void *accum, uint32_t accum_pitch_px, const void *reveal,
+                             uint32_t reveal_pitch_px, uint32_t width, uint32_t height, float *hdr,
+                             uint32_t hdr_pitch_px, uint32_t flags, void *stream);
+
 /* Lighting with the extensions, optionally fused with the tonemap (valid only when
  * nothing else writes hdr in between, unlike the reference's sky/transparency
  * subpasses, render/pbr/mod.rs:420-434).  `out` is float4 per pixel for

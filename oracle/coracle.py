@@ -93,3 +93,31 @@ def fxaa(ldr, row_begin=0, row_count=None, nthreads=0):
     lib().milo_fxaa(_p(ldr, ctypes.c_uint32), ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(row_begin),
                     ctypes.c_int(row_count), _p(out, ctypes.c_uint32), ctypes.c_int(nthreads))
     return out
+
+
+def sky_hosek(depth, frame_ubo, params, hdr, y_offset=0, full_height=None, nthreads=0):
+    """oracle.mil_oracle.sky_hosek in FP32; hdr (h, w, 4) float32 is updated in place and returned."""
+    depth = np.ascontiguousarray(depth, np.float32)
+    h, w = depth.shape
+    ubo = np.ascontiguousarray(frame_ubo, np.float32).reshape(68)
+    prm = np.ascontiguousarray(params, np.float32).reshape(44)
+    hdr = np.ascontiguousarray(hdr, np.float32)
+    f = ctypes.c_float
+    lib().milo_sky_hosek(_p(depth, f), ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(y_offset),
+                         ctypes.c_int(h if full_height is None else full_height), _p(ubo, f), _p(prm, f), _p(hdr, f),
+                         ctypes.c_int(w), ctypes.c_int(nthreads))
+    return hdr
+
+
+def transparency_resolve(accum_f16, reveal_f16, hdr, nthreads=0):
+    """oracle.mil_oracle.transparency_resolve in FP32; accum (h, w, 4) float16, reveal (h, w) float16."""
+    accum = np.ascontiguousarray(accum_f16, np.float16)
+    reveal = np.ascontiguousarray(reveal_f16, np.float16)
+    h, w = reveal.shape
+    hdr = np.ascontiguousarray(hdr, np.float32)
+    u16 = ctypes.c_uint16
+    lib().milo_transparency_resolve(accum.view(np.uint16).ctypes.data_as(ctypes.POINTER(u16)), ctypes.c_int(w),
+                                    reveal.view(np.uint16).ctypes.data_as(ctypes.POINTER(u16)), ctypes.c_int(w),
+                                    ctypes.c_int(w), ctypes.c_int(h), _p(hdr, ctypes.c_float), ctypes.c_int(w),
+                                    ctypes.c_int(nthreads))
+    return hdr

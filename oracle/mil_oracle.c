@@ -334,6 +334,87 @@ void milo_fxaa(const uint32_t *ldr, int width, int height, int pitch_px, int row
         }
 }
 
+/*
+ * NEXT ROW f-4: the Hosek-Wilkie sky subpass, renderer/shaders/sky_hosek_frag.glsl:28-60 (+ sky_hosek_vert.glsl),
+ * drawn at render/mod.rs:221-226 into hdr.  The vertex stage puts the sky mesh at depth (w - 1e-5) / w and the
+ * pipeline tests LessOrEqual without depth writes (render/hosek/mod.rs:58-64): the sky lands on the texels still
+ * at the clear depth 1.0 (or one ulp below: 1 - 1e-5/w rounds to 0x3F7FFFFF for w <= 200).  The fragment's
+ * interpolated `position` lies on the view ray of the pixel, so normalize(position - cameraPosition) is the
+ * normalised PositionFromDepth ray (fs_deferred_lighting.glsl:30-38) whatever the mesh is.
+ * exp / pow / acos are taken in double and rounded (the strict HIP kernel does the same), every other
+ * operation is one FP32 operation in GLSL order.  params: 11 vec3 at 16-byte stride (A B C D E F G H I Z sun).
+ */
+static inline float f_exp(float x) { return (float)exp((double)x); }
+void milo_sky_hosek(const float *depth, int width, int height, int pitch_px, int y_offset, int full_height,
+                    const float *ubo, const float *params, float *hdr, int hdr_pitch_px, int nthreads)
+{
+    const float *inv_proj = ubo + 32, *inv_view = ubo + 48, *cam = ubo + 64;
+    const float res_x = (float)width, res_y = (float)full_height;
+    const float *A = params, *B = params + 4, *C = params + 8, *D = params + 12, *E = params + 16, *F = params + 20,
+                *G = params + 24, *H = params + 28, *I = params + 32, *Z = params + 36, *sun = params + 40;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const float d = depth[(size_t)y * pitch_px + x];
+            if (!(d >= 0.99999994f)) continue;                       /* depth test LessOrEqual fails: hdr untouched */
+            float cx = ((float)x + 0.5f) / res_x, cy = ((float)(y + y_offset) + 0.5f) / res_y;
+            float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
+            float vx = mrow(inv_proj, 0, px, py, d, 1.0f), vy = mrow(inv_proj, 1, px, py, d, 1.0f);
+            float vz = mrow(inv_proj, 2, px, py, d, 1.0f), vw = mrow(inv_proj, 3, px, py, d, 1.0f);
+            vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
+            v3 P = { mrow(inv_view, 0, vx, vy, vz, vw), mrow(inv_view, 1, vx, vy, vz, vw), mrow(inv_view, 2, vx, vy, vz, vw) };
+            v3 vd = normalize3((v3){ P.x - cam[0], P.y - cam[1], P.z - cam[2] });            /* :56-58 */
+            v3 s = { sun[0], sun[1], sun[2] };
+            const float cg = fmaxf(0.001f, dot3(s, vd));                                      /* :46 */
+            const float ct = fmaxf(0.001f, (vd.x * 0.0f + vd.y * 1.0f) + vd.z * 0.0f);        /* :47 */
+            const float gamma = (float)acos((double)cg);                                      /* :49 */
+            float *o = hdr + ((size_t)y * hdr_pitch_px + x) * 4;
+            for (int c = 0; c < 3; c++) {
+                const float chi = (1.0f + cg * cg) / (float)pow((double)((1.0f + H[c] * H[c]) - (2.0f * H[c]) * cg), 1.5);   /* :39 */
+                const float left = 1.0f + A[c] * f_exp(B[c] / (ct + 0.01f));                  /* :41 */
+                const float right = (((C[c] + D[c] * f_exp(E[c] * gamma)) + (F[c] * cg) * cg) + G[c] * chi) + I[c] * sqrtf(ct);
+                o[c] = ((left * right) * Z[c]) * 0.05f;                                       /* :51, :58 */
+            }
+            o[3] = 1.0f;
+        }
+}
+
+/*
+ * NEXT ROW f-2: transparency resolve, renderer/shaders/fs_mcguire13_resolve.glsl:8-13 with the blend state of
+ * render/mcguire13/mod.rs:108-120 (colour and alpha: src * (1 - srcAlpha) + dst * srcAlpha), drawn at
+ * render/mod.rs:282-294 onto hdr.  accum: R16G16B16A16_SFLOAT, reveal: R16_SFLOAT (mcguire13/mod.rs:22-23).
+ */
+static inline float half_dec(uint16_t h)
+{
+    uint32_t e = (h >> 10) & 0x1F, m = h & 0x3FF;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf(1.0f + (float)m / 1024.0f, (int)e - 15);
+    return (h & 0x8000) ? -v : v;
+}
+void milo_transparency_resolve(const uint16_t *accum, int accum_pitch_px, const uint16_t *reveal, int reveal_pitch_px,
+                               int width, int height, float *hdr, int hdr_pitch_px, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < height; y++)
+        for (int x = 0; x < width; x++) {
+            const uint16_t *a = accum + ((size_t)y * accum_pitch_px + x) * 4;
+            const float r = half_dec(reveal[(size_t)y * reveal_pitch_px + x]);
+            const float den = fminf(5e4f, fmaxf(1e-4f, half_dec(a[3])));
+            float *o = hdr + ((size_t)y * hdr_pitch_px + x) * 4;
+            const float om = 1.0f - r;
+            for (int c = 0; c < 3; c++) o[c] = (half_dec(a[c]) / den) * om + o[c] * r;
+            o[3] = r * om + o[3] * r;
+        }
+}
+
 int milo_max_threads(void)
 {
 #ifdef _OPENMP

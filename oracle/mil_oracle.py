@@ -389,3 +389,49 @@ def fxaa(ldr_u32, row_begin=0, row_count=None, return_float=False):
     l_b = luma(b)
     rgb = np.where(((l_b < lmin) | (l_b > lmax))[..., None], a, b)    # :67-71
     return rgb if return_float else encode_b8g8r8a8_srgb(rgb)
+
+
+# --------------------------------------------------------------------------
+# NEXT ROW f-4: Hosek-Wilkie sky subpass (renderer/shaders/sky_hosek_frag.glsl:28-60, sky_hosek_vert.glsl,
+# draw render/mod.rs:221-226, pipeline render/hosek/mod.rs:46-76).  See oracle/mil_oracle.c for why the
+# pass covers exactly the texels still at the clear depth and why the view direction is the pixel's ray.
+# params: (11, 4) or flat 44 floats = A B C D E F G H I Z sun_direction at 16-byte stride (hosek/mod.rs:222-256).
+# --------------------------------------------------------------------------
+SKY_DEPTH_PASS = float(np.float32(0.99999994))
+
+
+def sky_hosek(depth_f32, frame_ubo, params, hdr, y_offset=0, full_height=None):
+    depth = np.asarray(depth_f32, dtype=np.float32)
+    h, w = depth.shape
+    full_height = h if full_height is None else full_height
+    f = unpack_frame_ubo(frame_ubo)
+    prm = np.asarray(params, np.float64).reshape(11, 4)[:, :3]
+    A, B, C, D, E, F, G, H, I, Z, sun = prm
+    P = position_from_depth(depth.astype(np.float64), w, full_height, y_offset, f['inv_projection'], f['inv_view'])
+    vd = _normalize(P - f['camera_position'])
+    cg = np.maximum(0.001, vd @ sun)[..., None]
+    ct = np.maximum(0.001, vd[..., 1])[..., None]
+    gamma = np.arccos(cg)
+    chi = (1.0 + cg * cg) / np.power(1.0 + H * H - 2.0 * H * cg, 1.5)
+    rad = (1.0 + A * np.exp(B / (ct + 0.01))) * (C + D * np.exp(E * gamma) + F * cg * cg + G * chi + I * np.sqrt(ct))
+    out = np.array(hdr, dtype=np.float64, copy=True)
+    sky = depth >= np.float32(SKY_DEPTH_PASS)
+    out[sky, :3] = (rad * Z * 0.05)[sky]
+    out[sky, 3] = 1.0
+    return out
+
+
+# --------------------------------------------------------------------------
+# NEXT ROW f-2: transparency resolve (renderer/shaders/fs_mcguire13_resolve.glsl:8-13; blend state
+# render/mcguire13/mod.rs:108-120: src * (1 - srcAlpha) + dst * srcAlpha for colour and alpha; draw
+# render/mod.rs:282-294).  accum RGBA16F, reveal R16F (mcguire13/mod.rs:22-23).
+# --------------------------------------------------------------------------
+def transparency_resolve(accum_f16, reveal_f16, hdr):
+    accum = np.asarray(accum_f16, np.float16).astype(np.float64)
+    r = np.asarray(reveal_f16, np.float16).astype(np.float64)
+    hdr = np.asarray(hdr, np.float64)
+    src = accum[..., :3] / np.minimum(5e4, np.maximum(np.float64(np.float32(1e-4)), accum[..., 3]))[..., None]
+    out = np.empty_like(hdr)
+    out[..., :3] = src * (1.0 - r)[..., None] + hdr[..., :3] * r[..., None]
+    out[..., 3] = r * (1.0 - r) + hdr[..., 3] * r
+    return out

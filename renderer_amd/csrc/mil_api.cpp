@@ -15,6 +15,7 @@
 static_assert(sizeof(mil_frame_matrix_data) == 272, "FrameMatrixData is 272 bytes (render/ubo.rs:28-41)");
 static_assert(sizeof(mil_directional_light) == 32, "DirectionalLight std140 stride is 32 (render/ubo.rs:54-63)");
 static_assert(sizeof(mil_point_light) == 32, "point light shares the 32-byte stride");
+static_assert(sizeof(mil_hosek_wilkie_params) == 176, "HosekWilkieParams is 11 vec3 at 16-byte stride (render/hosek/mod.rs:222-256)");
 static_assert(sizeof(mil_push_constants) == 12, "push constants are 12 bytes (fs_deferred_lighting.glsl:24-27)");
 
 namespace {
@@ -172,6 +173,30 @@ int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, co
     return MIL_OK;
 }
 
+// fast path: world.xyz - cam = ((inv_view - [0|cam]) * (v / v.w)).xyz with v = inv_proj * clip and
+// clip = (x*sx+ox, y*sy+oy, depth, 1): fold everything acting on (x, y_global, depth, 1) into one 4x4, in double
+void fold_position_matrix(const mil_frame_matrix_data *f, float res_x, float res_y, float *out16)
+{
+    const float *ip = f->inv_projection, *iv = f->inv_view;   // column-major: m[c*4 + r]
+    double C[4][4] = { { 2.0 / res_x, 0, 0, 1.0 / res_x - 1.0 }, { 0, 2.0 / res_y, 0, 1.0 / res_y - 1.0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    double PC[4][4], A[4][4];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) {
+            double a = 0;
+            for (int k = 0; k < 4; k++) a += (double)ip[k * 4 + r] * C[k][c];
+            PC[r][c] = a;
+        }
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) {
+            double a = 0;
+            for (int k = 0; k < 4; k++) a += ((double)iv[k * 4 + r] - (k == 3 ? (double)f->camera_position[r] : 0.0)) * PC[k][c];
+            A[r][c] = a;   // rows 0-2 yield P - cameraPosition
+        }
+    for (int c = 0; c < 4; c++) A[3][c] = PC[3][c];
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) out16[r * 4 + c] = (float)A[r][c];
+}
+
 void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_matrix_data *f, const mil_push_constants *push)
 {
     memset(&p, 0, sizeof(p));
@@ -183,28 +208,7 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
     p.res_x = push->resolution[0]; p.res_y = push->resolution[1];
     p.sx = 2.0f / p.res_x; p.ox = 1.0f / p.res_x - 1.0f;
     p.sy = 2.0f / p.res_y; p.oy = 1.0f / p.res_y - 1.0f;
-    // fast path: world.xyz - cam = ((inv_view - [0|cam]) * (v / v.w)).xyz = (inv_view * v).xyz / v.w with v = inv_proj * clip and
-    // clip = (x*sx+ox, y*sy+oy, depth, 1): fold everything acting on (x, y_global, depth, 1) into one 4x4, in double
-    {
-        const float *ip = f->inv_projection, *iv = f->inv_view;   // column-major: m[c*4 + r]
-        double C[4][4] = { { 2.0 / p.res_x, 0, 0, 1.0 / p.res_x - 1.0 }, { 0, 2.0 / p.res_y, 0, 1.0 / p.res_y - 1.0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
-        double PC[4][4], A[4][4];
-        for (int r = 0; r < 4; r++)
-            for (int c = 0; c < 4; c++) {
-                double a = 0;
-                for (int k = 0; k < 4; k++) a += (double)ip[k * 4 + r] * C[k][c];
-                PC[r][c] = a;
-            }
-        for (int r = 0; r < 3; r++)
-            for (int c = 0; c < 4; c++) {
-                double a = 0;
-                for (int k = 0; k < 4; k++) a += ((double)iv[k * 4 + r] - (k == 3 ? (double)f->camera_position[r] : 0.0)) * PC[k][c];
-                A[r][c] = a;   // rows 0-2 yield P - cameraPosition
-            }
-        for (int c = 0; c < 4; c++) A[3][c] = PC[3][c];
-        for (int r = 0; r < 4; r++)
-            for (int c = 0; c < 4; c++) p.pos_m[r * 4 + c] = (float)A[r][c];
-    }
+    fold_position_matrix(f, p.res_x, p.res_y, p.pos_m);
     p.tiles_x = (gb->width + MIL_TILE - 1) / MIL_TILE;
     p.tiles_y = (gb->height + MIL_TILE - 1) / MIL_TILE;
     for (uint32_t i = 0; i < MIL_MAX_ROW_ORDER; i++) p.row_order[i] = (uint16_t)i;
@@ -456,6 +460,44 @@ int mil_fxaa(mil_ctx *c, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t wi
     p.row_begin = row_begin; p.row_count = row_count;
     if (flags & MIL_FLAG_STRICT) mil::strict::launch_fxaa(p, (hipStream_t)stream);
     else mil::fast::launch_fxaa(p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream);
+}
+
+int mil_sky_hosek(mil_ctx *c, const float *depth, uint32_t depth_pitch_px, uint32_t width, uint32_t height, uint32_t y_offset,
+                  const mil_frame_matrix_data *frame, const mil_push_constants *push, const mil_hosek_wilkie_params *params,
+                  float *hdr, uint32_t hdr_pitch_px, uint32_t flags, void *stream)
+{
+    if (!c || !depth || !frame || !push || !params || !hdr || width == 0 || height == 0) return MIL_ERR_BAD_ARG;
+    if (depth_pitch_px < width || hdr_pitch_px < width) return MIL_ERR_BAD_ARG;
+    if (!(push->resolution[0] >= 1.0f) || !(push->resolution[1] >= 1.0f) || (float)width > push->resolution[0]) return MIL_ERR_BAD_ARG;
+    if ((double)y_offset + (double)height > (double)push->resolution[1]) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    mil::SkyParams p;
+    memset(&p, 0, sizeof(p));
+    p.depth = depth; p.hdr = hdr; p.width = width; p.height = height; p.depth_pitch = depth_pitch_px; p.hdr_pitch = hdr_pitch_px;
+    p.y_offset = y_offset;
+    memcpy(p.inv_proj, frame->inv_projection, 64); memcpy(p.inv_view, frame->inv_view, 64); memcpy(p.cam, frame->camera_position, 12);
+    p.res_x = push->resolution[0]; p.res_y = push->resolution[1];
+    fold_position_matrix(frame, p.res_x, p.res_y, p.pos_m);
+    memcpy(p.hw, params, sizeof(p.hw));
+    if (flags & MIL_FLAG_STRICT) mil::strict::launch_sky(p, (hipStream_t)stream);
+    else mil::fast::launch_sky(p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream);
+}
+
+int mil_transparency_resolve(mil_ctx *c, const void *accum, uint32_t accum_pitch_px, const void *reveal, uint32_t reveal_pitch_px,
+                             uint32_t width, uint32_t height, float *hdr, uint32_t hdr_pitch_px, uint32_t flags, void *stream)
+{
+    if (!c || !accum || !reveal || !hdr || width == 0 || height == 0) return MIL_ERR_BAD_ARG;
+    if (accum_pitch_px < width || reveal_pitch_px < width || hdr_pitch_px < width) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    mil::ResolveParams p;
+    p.accum = (const uint16_t *)accum; p.reveal = (const uint16_t *)reveal; p.hdr = hdr; p.width = width; p.height = height;
+    p.accum_pitch = accum_pitch_px; p.reveal_pitch = reveal_pitch_px; p.hdr_pitch = hdr_pitch_px;
+    if (flags & MIL_FLAG_STRICT) mil::strict::launch_resolve(p, (hipStream_t)stream);
+    else mil::fast::launch_resolve(p, (hipStream_t)stream);
     return finish(c, nullptr, (hipStream_t)stream);
 }
 

@@ -1114,6 +1114,99 @@ __global__ __launch_bounds__(256) void k_fxaa(const FxaaParams p)
 }
 
 // ---------------------------------------------------------------------------------
+// K6 (next row f-4): Hosek-Wilkie sky subpass as a screen-space pass, renderer/shaders/sky_hosek_frag.glsl:28-60
+// (draw render/mod.rs:221-226; depth test LessOrEqual at z = w - 1e-5, render/hosek/mod.rs:58-64,
+// sky_hosek_vert.glsl:19-20): texels still at the clear depth get hdr = (radiance * 0.05, 1), the others keep
+// hdr.  The interpolated mesh position of the fragment lies on the pixel's view ray, so the view direction is
+// the normalised PositionFromDepth ray.  Block 64 x 4; a wave without a sky texel returns after one load.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sky(const SkyParams p)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.width || y >= p.height) return;
+    const float d = p.depth[(size_t)y * p.depth_pitch + x];
+    const bool sky = d >= 0.99999994f;
+    if (__builtin_amdgcn_ballot_w64(sky) == 0) return;
+    const float *A = p.hw[0], *B = p.hw[1], *C = p.hw[2], *D = p.hw[3], *E = p.hw[4], *F = p.hw[5], *G = p.hw[6], *H = p.hw[7],
+                *I = p.hw[8], *Z = p.hw[9], *sun = p.hw[10];
+    float r3[3];
+#if MIL_STRICT
+    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
+    float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
+    float vx = mrow(p.inv_proj, 0, px, py, d, 1.0f), vy = mrow(p.inv_proj, 1, px, py, d, 1.0f);
+    float vz = mrow(p.inv_proj, 2, px, py, d, 1.0f), vw = mrow(p.inv_proj, 3, px, py, d, 1.0f);
+    vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
+    f3 P = { mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
+    f3 vd = normalize3(f3{ P.x - p.cam[0], P.y - p.cam[1], P.z - p.cam[2] });                    // :56-58
+    const float cg = fmaxf(0.001f, dot3(f3{ sun[0], sun[1], sun[2] }, vd));                      // :46
+    const float ct = fmaxf(0.001f, (vd.x * 0.0f + vd.y * 1.0f) + vd.z * 0.0f);                   // :47
+    const float gamma = (float)acos((double)cg);                                                 // :49 (exp / pow / acos in double, as the oracle)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float chi = (1.0f + cg * cg) / (float)pow((double)((1.0f + H[c] * H[c]) - (2.0f * H[c]) * cg), 1.5);   // :39
+        const float left = 1.0f + A[c] * (float)exp((double)(B[c] / (ct + 0.01f)));              // :41
+        const float right = (((C[c] + D[c] * (float)exp((double)(E[c] * gamma))) + (F[c] * cg) * cg) + G[c] * chi) + I[c] * sqrtf(ct);
+        r3[c] = ((left * right) * Z[c]) * 0.05f;                                                 // :51, :58
+    }
+#else
+    const float xf = (float)x, yf = (float)(y + p.y_offset);
+    const float *m = p.pos_m;
+    // direction only: the w divide of PositionFromDepth is a positive scale the normalisation removes
+    f3 v = { __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, __builtin_fmaf(m[2], d, m[3]))),
+             __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, __builtin_fmaf(m[6], d, m[7]))),
+             __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, __builtin_fmaf(m[10], d, m[11]))) };
+    const float vw = __builtin_fmaf(m[12], xf, __builtin_fmaf(m[13], yf, __builtin_fmaf(m[14], d, m[15])));
+    const float rn = rsq_(dot3(v, v)) * (vw < 0.0f ? -1.0f : 1.0f);
+    const f3 vd = { v.x * rn, v.y * rn, v.z * rn };
+    const float cg = fmaxf(0.001f, dot3(f3{ sun[0], sun[1], sun[2] }, vd));
+    const float ct = fmaxf(0.001f, vd.y);
+    const float gamma = acosf(cg);
+    const float cg2 = cg * cg, sct = sqrt_(ct), ict = rcp_(ct + 0.01f);
+    const float LOG2E = 1.4426950408889634f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = __builtin_fmaf(-2.0f * H[c], cg, __builtin_fmaf(H[c], H[c], 1.0f));       // 1 + H^2 - 2 H cos(gamma)
+        const float chi = (1.0f + cg2) * rsq_(t) * rcp_(t);                                       // t^-1.5
+        const float left = __builtin_fmaf(A[c], __builtin_amdgcn_exp2f(B[c] * ict * LOG2E), 1.0f);
+        const float right = __builtin_fmaf(I[c], sct, __builtin_fmaf(G[c], chi, __builtin_fmaf(F[c], cg2,
+                            __builtin_fmaf(D[c], __builtin_amdgcn_exp2f(E[c] * gamma * LOG2E), C[c]))));
+        r3[c] = left * right * (Z[c] * 0.05f);
+    }
+#endif
+    if (sky) __builtin_nontemporal_store(v4f{ r3[0], r3[1], r3[2], 1.0f }, (v4f *)p.hdr + (size_t)y * p.hdr_pitch + x);
+}
+
+// ---------------------------------------------------------------------------------
+// K7 (next row f-2): transparency resolve, renderer/shaders/fs_mcguire13_resolve.glsl:8-13 with the blend of
+// render/mcguire13/mod.rs:108-120 (draw render/mod.rs:282-294): hdr = src * (1 - r) + hdr * r, src =
+// (accum.rgb / clamp(accum.a, 1e-4, 5e4), r).  Streaming: 8 + 2 + 16 B read, 16 B written per pixel; a wave
+// whose 64 texels all have revealage 1 and accum 0 (nothing transparent there) leaves hdr untouched:
+// 0 * 0 + hdr * 1 = hdr exactly for finite hdr.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= p.width || y >= p.height) return;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const h4 a = __builtin_nontemporal_load((const h4 *)p.accum + (size_t)y * p.accum_pitch + x);
+    const float r = (float)__builtin_nontemporal_load((const _Float16 *)p.reveal + (size_t)y * p.reveal_pitch + x);
+    const float ar = (float)a.x, ag = (float)a.y, ab = (float)a.z, aa = (float)a.w;
+#if !MIL_STRICT
+    if (__builtin_amdgcn_ballot_w64(!(r == 1.0f && ar == 0.0f && ag == 0.0f && ab == 0.0f)) == 0) return;
+#endif
+    v4f *dst = (v4f *)p.hdr + (size_t)y * p.hdr_pitch + x;
+    const v4f h = *dst;
+    const float den = fminf(5e4f, fmaxf(1e-4f, aa)), om = 1.0f - r;
+#if MIL_STRICT
+    const v4f o = { (ar / den) * om + h.x * r, (ag / den) * om + h.y * r, (ab / den) * om + h.z * r, r * om + h.w * r };
+#else
+    const float k = rcp_(den) * om;
+    const v4f o = { __builtin_fmaf(ar, k, h.x * r), __builtin_fmaf(ag, k, h.y * r), __builtin_fmaf(ab, k, h.z * r), __builtin_fmaf(r, om, h.w * r) };
+#endif
+    __builtin_nontemporal_store(o, dst);
+}
+
+// ---------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s)
@@ -1159,6 +1252,16 @@ void launch_fxaa(const FxaaParams &p, hipStream_t s)
 {
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.row_count + 3) / 4);
     hipLaunchKernelGGL(k_fxaa, grid, block, 0, s, p);
+}
+void launch_sky(const SkyParams &p, hipStream_t s)
+{
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    hipLaunchKernelGGL(k_sky, grid, block, 0, s, p);
+}
+void launch_resolve(const ResolveParams &p, hipStream_t s)
+{
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    hipLaunchKernelGGL(k_resolve, grid, block, 0, s, p);
 }
 #if !MIL_STRICT
 void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)

@@ -61,6 +61,22 @@ struct FxaaParams {
     uint32_t width, height, ldr_pitch, out_pitch, row_begin, row_count;
 };
 
+struct SkyParams {            // sky subpass: depth in, hdr in/out
+    const float *depth;
+    float *hdr;
+    uint32_t width, height, depth_pitch, hdr_pitch, y_offset;
+    float inv_proj[16], inv_view[16], cam[3];
+    float res_x, res_y;
+    float pos_m[16];          // fast path: folded camera-relative position matrix (as ShadeParams.pos_m)
+    float hw[11][4];          // A B C D E F G H I Z sun_direction
+};
+
+struct ResolveParams {        // transparency resolve: accum RGBA16F + reveal R16F in, hdr in/out
+    const uint16_t *accum, *reveal;
+    float *hdr;
+    uint32_t width, height, accum_pitch, reveal_pitch, hdr_pitch;
+};
+
 // implemented once per numeric mode
 namespace fast {
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
@@ -68,12 +84,16 @@ void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
 void launch_fxaa(const FxaaParams &p, hipStream_t s);
+void launch_sky(const SkyParams &p, hipStream_t s);
+void launch_resolve(const ResolveParams &p, hipStream_t s);
 }
 namespace strict {
 void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 void launch_fxaa(const FxaaParams &p, hipStream_t s);
+void launch_sky(const SkyParams &p, hipStream_t s);
+void launch_resolve(const ResolveParams &p, hipStream_t s);
 }
 
 } // namespace mil

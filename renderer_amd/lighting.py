@@ -24,7 +24,7 @@ TILE = 16
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
-           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa']
+           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve']
 
 
 class MilError(RuntimeError):
@@ -78,6 +78,8 @@ def load_library(path=LIB_PATH):
         lib.mil_light_ex.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras), vp, u32,
                                      ctypes.c_int, u32, vp]
         lib.mil_fxaa.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, u32, u32, vp]
+        lib.mil_sky_hosek.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, u32, vp]
+        lib.mil_transparency_resolve.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp, u32, u32, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
         _lib = lib
     return _lib
@@ -168,6 +170,29 @@ class LightingPass:
         self._check(self.lib.mil_fxaa(self.ctx, ldr.data_ptr(), ldr.stride(0), w, h, row_begin, row_count, out.data_ptr(),
                                       out.stride(0), FLAG_STRICT if strict else 0, self._stream(stream)))
         return out
+
+    def sky_hosek(self, gb, frame, params, hdr, strict=False, stream=None):
+        """The sky draw (render/mod.rs:221-226) as a screen-space pass over hdr (in place).
+        params: 44 floats = HosekWilkieParams (render/hosek/mod.rs:222-256)."""
+        d = gb['depth']
+        h, w = d.shape
+        frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+        prm = np.ascontiguousarray(params, np.float32).reshape(44)
+        push = self._push(gb, 0)
+        self._check(self.lib.mil_sky_hosek(self.ctx, d.data_ptr(), d.stride(0), w, h, gb.get('y_offset', 0), _np_ptr(frame),
+                                           _np_ptr(push), _np_ptr(prm), hdr.data_ptr(), hdr.stride(0) // 4,
+                                           FLAG_STRICT if strict else 0, self._stream(stream)))
+        return hdr
+
+    def transparency_resolve(self, accum, reveal, hdr, strict=False, stream=None):
+        """The resolve draw (render/mod.rs:282-294): accum (h, w, 4) float16, reveal (h, w) float16, hdr in place."""
+        t = self.torch
+        assert accum.dtype == t.float16 and reveal.dtype == t.float16 and hdr.dtype == t.float32
+        h, w = reveal.shape
+        self._check(self.lib.mil_transparency_resolve(self.ctx, accum.data_ptr(), accum.stride(0) // 4, reveal.data_ptr(),
+                                                      reveal.stride(0), w, h, hdr.data_ptr(), hdr.stride(0) // 4,
+                                                      FLAG_STRICT if strict else 0, self._stream(stream)))
+        return hdr
 
     def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,
                  flags=0, out=None, stream=None):

@@ -370,6 +370,46 @@ def test_full_chain_4k_gbuffer_to_swapchain(lp):
     assert (d > 1).mean() <= 5e-3
 
 
+# ------------------------------------------------------------------ next rows f-4 (sky) and f-2 (transparency resolve)
+def test_sky_hosek(lp, coracle):
+    from test_oracle_kat import sky_test_params
+    prm = sky_test_params()
+    for (w, h) in [(320, 180), (67, 35)]:
+        gb, frame, dl, _, _ = make_scene('sweep', w, h)
+        depth = gb['depth'].cpu().numpy()
+        hdr0 = lp.light_directional(gb, frame, dl)
+        ref32 = coracle.sky_hosek(depth, frame, prm, hdr0.cpu().numpy())
+        ref64 = mo.sky_hosek(depth, frame, prm, hdr0.cpu().numpy())
+        strict = lp.sky_hosek(gb, frame, prm, hdr0.clone(), strict=True).cpu().numpy()
+        # FP32 in GLSL order with exp / pow / acos taken in double on both sides: equal up to the last ulp of those
+        np.testing.assert_allclose(strict, ref32, rtol=3e-7, atol=0)
+        assert (strict != ref32).mean() < 1e-3
+        fast = lp.sky_hosek(gb, frame, prm, hdr0.clone()).cpu().numpy()
+        assert np.all(np.abs(fast - ref64) <= 1e-3 + 1e-4 * np.abs(ref64))
+        sky = depth >= 1
+        assert np.array_equal(fast[~sky], hdr0.cpu().numpy()[~sky]) and np.all(fast[sky][:, 3] == 1)
+        y0, y1 = 16, 32                                                     # strip == rows of the whole frame, bit for bit
+        strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+        strip['y_offset'] = y0
+        for st in (False, True):
+            full = lp.sky_hosek(gb, frame, prm, hdr0.clone(), strict=st)
+            assert torch.equal(lp.sky_hosek(strip, frame, prm, hdr0[y0:y1].clone(), strict=st), full[y0:y1])
+
+
+def test_transparency_resolve(lp, coracle):
+    from test_oracle_kat import transparency_test_inputs
+    for (w, h) in [(256, 144), (65, 5)]:
+        acc, rev = transparency_test_inputs(h, w, seed=w)
+        hdr0 = np.random.RandomState(2).rand(h, w, 4).astype(np.float32) * 4
+        ta, tr, th = torch.from_numpy(acc).to(DEV), torch.from_numpy(rev).to(DEV), torch.from_numpy(hdr0).to(DEV)
+        strict = lp.transparency_resolve(ta, tr, th.clone(), strict=True).cpu().numpy()
+        assert_bits_equal(strict, coracle.transparency_resolve(acc, rev, hdr0.copy()), 'resolve strict')
+        fast = lp.transparency_resolve(ta, tr, th.clone()).cpu().numpy()
+        ref = mo.transparency_resolve(acc, rev, hdr0)
+        assert np.all(np.abs(fast - ref) <= 1e-3 + 1e-4 * np.abs(ref))
+        assert np.array_equal(fast[rev == 1], hdr0[rev == 1])               # nothing transparent there: hdr untouched
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE.json sizes)
 def test_4k_properties(lp):
     w, h = 3840, 2160

@@ -294,3 +294,68 @@ def test_fxaa_golden_fixture(coracle):
     np.testing.assert_array_equal(coracle.fxaa(z['ldr']), z['srgb8_c32'])
     d = np.abs(_ch(mo.fxaa(z['ldr'])) - _ch(z['srgb8_f64'])).max()
     assert d == 0
+
+
+# ------------------------------------------------------------------ next rows f-4 (sky) and f-2 (transparency resolve)
+def sky_test_params():
+    """Synthetic HosekWilkieParams (the model's dataset evaluation is CPU-side and out of scope): magnitudes of
+    a turbidity-3 configuration, distinct per channel."""
+    prm = np.zeros((11, 4), np.float32)
+    prm[:, :3] = [[-1.1, -1.15, -1.2], [-0.2, -0.25, -0.3], [5.0, 4.0, 2.5], [1.0, 1.2, 0.9], [-3.0, -3.5, -2.5], [0.4, 0.3, 0.5],
+                  [0.15, 0.2, 0.1], [0.7, 0.6, 0.65], [0.6, 0.7, 0.5], [12.0, 14.0, 18.0], [0.3, 0.8, 0.52]]
+    prm[10, :3] /= np.linalg.norm(prm[10, :3])
+    return prm
+
+
+def test_kat9_sky_and_resolve_hand_derived(coracle):
+    # sky: A = D = F = G = I = 0, C = (1, 2, 4), Z = (1, 1, .5): radiance = (1 + 0) * C * Z * 0.05 = (.05, .1, .1) on
+    # texels at the clear depth, untouched elsewhere (sky_hosek_frag.glsl:41,51,58)
+    prm = np.zeros((11, 4), np.float32)
+    prm[2, :3], prm[9, :3], prm[10, :3] = (1, 2, 4), (1, 1, .5), (0, 1, 0)
+    depth = np.array([[1.0, 0.5], [np.float32(0.99999994), 0.999999]], np.float32)
+    frame = synth.sweep_camera(2, 2).frame_matrix_data()
+    hdr = np.full((2, 2, 4), 7.0, np.float32)
+    for out in (mo.sky_hosek(depth, frame, prm, hdr), coracle.sky_hosek(depth, frame, prm, hdr.copy())):
+        np.testing.assert_allclose(out[0, 0], [.05, .1, .1, 1], rtol=1e-6)
+        np.testing.assert_allclose(out[1, 0], [.05, .1, .1, 1], rtol=1e-6)
+        assert np.all(out[0, 1] == 7) and np.all(out[1, 1] == 7)
+    # resolve: accum (1, 2, 3, 2), reveal .25, hdr (4, 4, 4, 1): src = (.5, 1, 1.5); out = src * .75 + 4 * .25 =
+    # (1.375, 1.75, 2.125), alpha = .25 * .75 + 1 * .25 = .4375 (fs_mcguire13_resolve.glsl:12, mcguire13/mod.rs:108-120)
+    acc = np.array([[[1, 2, 3, 2]]], np.float16)
+    rev = np.array([[0.25]], np.float16)
+    h0 = np.array([[[4, 4, 4, 1]]], np.float32)
+    for out in (mo.transparency_resolve(acc, rev, h0), coracle.transparency_resolve(acc, rev, h0.copy())):
+        np.testing.assert_array_equal(out[0, 0], [1.375, 1.75, 2.125, 0.4375])
+    # accum.a below 1e-4 clamps: (1e-5 stored as half) -> divide by 1e-4
+    acc = np.array([[[1, 0, 0, 1e-5]]], np.float16)
+    out = coracle.transparency_resolve(acc, np.array([[0.0]], np.float16), h0.copy())
+    np.testing.assert_allclose(out[0, 0, 0], 1.0 / np.float32(1e-4), rtol=1e-6)
+
+
+def transparency_test_inputs(h, w, seed=1):
+    rng = np.random.RandomState(seed)
+    acc = (rng.rand(h, w, 4) * np.array([3, 3, 3, 2])).astype(np.float16)
+    empty = rng.rand(h, w) < 0.5
+    acc[empty] = 0
+    rev = rng.rand(h, w).astype(np.float16)
+    rev[empty] = 1                                      # cleared: accum 0, reveal 1 (render/mod.rs:134-135)
+    return acc, rev
+
+
+def test_sky_and_resolve_two_restatements_agree(coracle):
+    W, H = 160, 90
+    cam = synth.sweep_camera(W, H)
+    gb = synth.to_numpy(synth.scene_sweep(W, H, cam))
+    frame = cam.frame_matrix_data()
+    hdr0 = np.random.RandomState(0).rand(H, W, 4).astype(np.float32)
+    a, b = mo.sky_hosek(gb['depth'], frame, sky_test_params(), hdr0), coracle.sky_hosek(gb['depth'], frame, sky_test_params(), hdr0.copy())
+    sky = gb['depth'] >= 1
+    assert 0.2 < sky.mean() < 0.8
+    np.testing.assert_allclose(b, a, rtol=2e-5, atol=1e-6)
+    assert np.array_equal(b[~sky], hdr0[~sky]) and np.all(b[sky][:, 3] == 1)
+    y0, y1 = 16, 48                                     # strip == rows of the whole frame
+    np.testing.assert_array_equal(coracle.sky_hosek(gb['depth'][y0:y1], frame, sky_test_params(), hdr0[y0:y1].copy(), y_offset=y0, full_height=H), b[y0:y1])
+    acc, rev = transparency_test_inputs(H, W)
+    a, b = mo.transparency_resolve(acc, rev, hdr0), coracle.transparency_resolve(acc, rev, hdr0.copy())
+    np.testing.assert_allclose(b, a, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(b[rev == 1], hdr0[rev == 1])  # nothing transparent: hdr untouched
