@@ -68,6 +68,25 @@ def fx(strict=False):
 if not os.environ.get('K1ONLY') and not os.environ.get('HLONLY'):
     print(f'{"fxaa R11G11B10F -> sRGB8":50s} {timeit(fx()):9.1f} us')
     print(f'{"fxaa strict":50s} {timeit(fx(True)):9.1f} us')
+if not os.environ.get('K1ONLY') and not os.environ.get('HLONLY'):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+    from test_oracle_kat import sky_test_params
+    prm = sky_test_params()
+    acc = torch.zeros((H, W, 4), dtype=torch.float16, device=dev); rev = torch.ones((H, W), dtype=torch.float16, device=dev)
+    acc[H // 3: 2 * H // 3, W // 4: 3 * W // 4] = torch.tensor([0.5, 0.4, 0.3, 0.8], dtype=torch.float16, device=dev); rev[H // 3: 2 * H // 3, W // 4: 3 * W // 4] = 0.4
+    def sk():
+        i = it[0] % 3; it[0] += 1
+        lp.sky_hosek(gbs[i], frame, prm, hdrs[i])
+    def rs():
+        i = it[0] % 3; it[0] += 1
+        lp.transparency_resolve(acc, rev, hdrs[i])
+    def chain():
+        i = it[0] % 3; it[0] += 1
+        lp.light_ex(gbs[i], frame, dl, pl, amb, sh, out=hdrs[i]); lp.sky_hosek(gbs[i], frame, prm, hdrs[i])
+        lp.transparency_resolve(acc, rev, hdrs[i]); lp.tonemap(hdrs[i], 1, out=ldrs[i]); lp.fxaa(ldrs[i], out=outs[i])
+    print(f'{"sky (49 % of the texels)":50s} {timeit(sk):9.1f} us')
+    print(f'{"transparency resolve (1/6 of the frame covered)":50s} {timeit(rs):9.1f} us')
+    print(f'{"whole frame: light+sky+resolve+tonemap+fxaa":50s} {timeit(chain):9.1f} us')
 # memcpy reference: copy 16 B/px in, 16 B/px out
 if os.environ.get('K1ONLY') or os.environ.get('HLONLY'): sys.exit(0)
 a = torch.empty(W * H * 4, device=dev); b = torch.empty_like(a)
