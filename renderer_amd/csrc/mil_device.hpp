@@ -379,13 +379,14 @@ DEV bool point_test(const Px &q, v4f a, f3 &Lv, float &d2)
 }
 DEV void point_eval(const Px &q, v4f a, v4f b, f3 Lv, float d2, bool on, f3 &res)
 {
-    float inv = rsq_(fmaxf(d2, 1e-12f));
+    // Out-of-range lanes get att = 0 by SELECT (the window w can round to a tiny non-zero value just outside the
+    // radius, and a culled tile list must not change a bit).  Everything the BRDF forms from a finite pixel is
+    // finite or clamped (den >= NdotV * alpha > 0, t >= alpha^2 > 0, |L| <= 1e6 |Lv|), so radiance 0 adds exactly 0.
+    float inv = rsq_(d2 + 1e-12f);
     V3<float> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
     float qq = d2 * b.w, w = sat(__builtin_fmaf(-qq, qq, 1.0f));
-    float att = on ? (w * w) * rcp_(d2 + 1e-4f) : 0.0f;         // select, not multiply: 0 stays 0 for non-finite BRDF values
-    V3<float> t = { 0.0f, 0.0f, 0.0f };
-    eval_light_unit<float>(q, L, V3<float>{ b.x * att, b.y * att, b.z * att }, t);
-    if (on) { res.x += t.x; res.y += t.y; res.z += t.z; }
+    float att = on ? (w * w) * rcp_(d2 + 1e-4f) : 0.0f;
+    eval_light_unit<float>(q, L, V3<float>{ b.x * att, b.y * att, b.z * att }, res);
 }
 DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
 {
@@ -403,16 +404,12 @@ DEV v2f point_d2_2(const Px2 &q, v4f a, V3<v2f> &Lv)
 }
 DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1, V3<v2f> &res)
 {
-    v2f inv = rsq_(max_(d2, (v2f)(1e-12f)));
+    v2f inv = rsq_(d2 + 1e-12f);
     V3<v2f> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
     v2f qq = d2 * b.w, w = sat(fma_(-qq, qq, (v2f)(1.0f)));
     v2f att = (w * w) * rcp_(d2 + 1e-4f);
-    att = v2f{ on0 ? att.x : 0.0f, on1 ? att.y : 0.0f };
-    V3<v2f> t = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
-    eval_light_unit<v2f>(q, L, V3<v2f>{ b.x * att, b.y * att, b.z * att }, t);
-    res.x += v2f{ on0 ? t.x.x : 0.0f, on1 ? t.x.y : 0.0f };
-    res.y += v2f{ on0 ? t.y.x : 0.0f, on1 ? t.y.y : 0.0f };
-    res.z += v2f{ on0 ? t.z.x : 0.0f, on1 ? t.z.y : 0.0f };
+    att = v2f{ on0 ? att.x : 0.0f, on1 ? att.y : 0.0f };          // see point_eval
+    eval_light_unit<v2f>(q, L, V3<v2f>{ b.x * att, b.y * att, b.z * att }, res);
 }
 DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t u2, f3 &res)
 {
