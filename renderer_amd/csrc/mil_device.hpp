@@ -319,7 +319,7 @@ DEV void setup_pixel(Px &q, const ShadeParams &, Pos pos, uint32_t u1, uint32_t 
 
 // light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow].
 //   colour = dif + tint * (F0 + (f90 - F0) w^5) * D * Vis = dif + (G0 + G1 w^5) * DV
-template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T LdotH, V3<T> rad, V3<T> &res)
+template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T LdotH, V3<T> col, T scale, V3<T> &res)
 {
     T x2 = NdotH * NdotH;
     T k = q.alpha * rcp_(fma_(x2, q.am1, (T)1.0f));                      // alpha / ((1-x2) + x2*alpha^2)
@@ -330,36 +330,34 @@ template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T Ld
     T cx = fma_(fma_(q.G1.x, w5, q.G0.x), DV, q.dif.x);
     T cy = fma_(fma_(q.G1.y, w5, q.G0.y), DV, q.dif.y);
     T cz = fma_(fma_(q.G1.z, w5, q.G0.z), DV, q.dif.z);
-    res.x = fma_(cx, rad.x * NdotL, res.x);
-    res.y = fma_(cy, rad.y * NdotL, res.y);
-    res.z = fma_(cz, rad.z * NdotL, res.z);
+    T sN = scale * NdotL;                                                // radiance = col * scale, scale = attenuation or shadow
+    res.x = fma_(cx, col.x * sN, res.x);
+    res.y = fma_(cy, col.y * sN, res.y);
+    res.z = fma_(cz, col.z * sN, res.z);
 }
 // general L (directional lights are not normalised by the shader, inc_structs.glsl:12-16)
-template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> rad, V3<T> &res)
+template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
     V3<T> H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
     T rh = rsq_(dot3(H, H));
-    eval_tail<T>(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), rad, res);
+    eval_tail<T>(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), col, scale, res);
 }
 // |L| = 1 (point lights, normalised here):  |L+V|^2 = 2 + 2 L.V,  N.H = (N.L + N.V) / |L+V|,  L.H = (1 + L.V) / |L+V|
-template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> rad, V3<T> &res)
+template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
     T nl = dot3(q.N, L), lv = dot3(L, q.V);
     T rh = rsq_(fma_((T)2.0f, lv, (T)2.0f));
-    eval_tail<T>(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(fma_(lv, rh, rh)), rad, res);
+    eval_tail<T>(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(fma_(lv, rh, rh)), col, scale, res);
 }
 
 DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
 {
-    f3 rad = { d.b.x, d.b.y, d.b.z };
-    if (use_shadow) { rad.x *= shadow; rad.y *= shadow; rad.z *= shadow; }
-    eval_light<float>(q, f3{ d.a.x, d.a.y, d.a.z }, rad, res);
+    eval_light<float>(q, f3{ d.a.x, d.a.y, d.a.z }, f3{ d.b.x, d.b.y, d.b.z }, use_shadow ? shadow : 1.0f, res);
 }
 DEV void add_directional2(const Px2 &q, DirRec d, v2f shadow, bool use_shadow, V3<v2f> &res)
 {
-    V3<v2f> rad = { (v2f)(d.b.x), (v2f)(d.b.y), (v2f)(d.b.z) };
-    if (use_shadow) { rad.x *= shadow; rad.y *= shadow; rad.z *= shadow; }
-    eval_light<v2f>(q, V3<v2f>{ (v2f)(d.a.x), (v2f)(d.a.y), (v2f)(d.a.z) }, rad, res);
+    eval_light<v2f>(q, V3<v2f>{ (v2f)(d.a.x), (v2f)(d.a.y), (v2f)(d.a.z) }, V3<v2f>{ (v2f)(d.b.x), (v2f)(d.b.y), (v2f)(d.b.z) },
+                    use_shadow ? shadow : (v2f)(1.0f), res);
 }
 
 DEV float point_d2(const Px &q, v4f a, f3 &Lv)
@@ -386,7 +384,7 @@ DEV void point_eval(const Px &q, v4f a, v4f b, f3 Lv, float d2, bool on, f3 &res
     V3<float> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
     float qq = d2 * b.w, w = sat(__builtin_fmaf(-qq, qq, 1.0f));
     float att = on ? (w * w) * rcp_(d2 + 1e-4f) : 0.0f;
-    eval_light_unit<float>(q, L, V3<float>{ b.x * att, b.y * att, b.z * att }, res);
+    eval_light_unit<float>(q, L, V3<float>{ b.x, b.y, b.z }, att, res);
 }
 DEV void add_point(const Px &q, v4f a, v4f b, f3 &res)
 {
@@ -409,7 +407,7 @@ DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1
     v2f qq = d2 * b.w, w = sat(fma_(-qq, qq, (v2f)(1.0f)));
     v2f att = (w * w) * rcp_(d2 + 1e-4f);
     att = v2f{ on0 ? att.x : 0.0f, on1 ? att.y : 0.0f };          // see point_eval
-    eval_light_unit<v2f>(q, L, V3<v2f>{ b.x * att, b.y * att, b.z * att }, res);
+    eval_light_unit<v2f>(q, L, V3<v2f>{ (v2f)(b.x), (v2f)(b.y), (v2f)(b.z) }, att, res);
 }
 DEV void add_ambient(const Px &q, const ShadeParams &p, uint32_t u2, f3 &res)
 {
