@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--sets', type=int, default=3, help='rotating buffer sets (cold-cache protocol)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-extra', action='store_true', help='skip the 4K/1-light HBM-bound side measurement')
+    ap.add_argument('--serial', action='store_true', help='one stream: lighting and tonemap back to back (no overlap across frames)')
     ap.add_argument('--fused', action='store_true', help='one kernel: lighting + tonemap -> sRGB8 (20 B/px)')
     ap.add_argument('--flags', type=int, default=0, help='extra MIL_FLAG_* bits (experiments)')
     return ap.parse_args()
@@ -111,8 +112,8 @@ def kernel_burst(torch, lighting, lp, inp, n, fused, flags, which='light'):
     return e0.elapsed_time(e1) / n
 
 
-def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0):
-    """Returns (seconds for `steps` steps [max over ranks], mean ms of the lighting kernel, mean ms tonemap)."""
+def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0, pipelined=True):
+    """Returns seconds for `steps` steps [max over ranks]."""
     from renderer_amd import sharding
     dev = lp.device
     n_sets = len(inp['sets'])
@@ -122,6 +123,12 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
     slots = [[torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(n_sets)] \
         if (world > 1 and rank == 0) else [None] * n_sets
     pending = [[] for _ in range(n_sets)]
+    # Two HIP streams: the tonemap of frame i (HBM-bound) runs beside the lighting of frame i + 1 (VALU-bound).
+    main = torch.cuda.current_stream(dev)
+    post = torch.cuda.Stream(device=dev) if pipelined else main
+    lit_done = [torch.cuda.Event() for _ in range(n_sets)]
+    tone_done = [torch.cuda.Event() for _ in range(n_sets)]
+    used = [False] * n_sets
 
     def step(i, ev=None):
         s = i % n_sets
@@ -129,23 +136,22 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
             q.wait()
         pending[s] = []
         gb = inp['sets'][s]
-        if ev:
-            ev[0].record()
         if fused:
             lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_SRGB8,
                         flags=flags, out=out[s])
-            if ev:
-                ev[1].record()
         else:
+            if used[s]:
+                main.wait_event(tone_done[s])            # hdr[s] is still being read by the tonemap of n_sets steps ago
             lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_HDR,
-                        flags=flags, out=hdr[s])
-            if ev:
-                ev[1].record()
-            lp.tonemap(hdr[s], lighting.OUT_SRGB8, out=out[s])
-            if ev:
-                ev[2].record()
+                        flags=flags, out=hdr[s], stream=main)
+            lit_done[s].record(main)
+            post.wait_event(lit_done[s])
+            lp.tonemap(hdr[s], lighting.OUT_SRGB8, out=out[s], stream=post)
+            tone_done[s].record(post)
+            used[s] = True
         if world > 1:
-            pending[s] = sharding.gather_frames(out[s], slots[s], dst=0, async_op=True)
+            with torch.cuda.stream(post):
+                pending[s] = sharding.gather_frames(out[s], slots[s], dst=0, async_op=True)
 
     def drain():
         for s in range(n_sets):
@@ -157,25 +163,22 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
     for i in range(warmup):
         step(i)
     drain()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     if dist is not None and world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(warmup + i, events[i])
+        step(warmup + i)
     drain()
     if dist is not None and world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    light_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in events]))
-    tone_ms = 0.0 if fused else float(np.mean([e[1].elapsed_time(e[2]) for e in events]))
     dt = t1 - t0
     if dist is not None and world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    return dt, light_ms, tone_ms
+    return dt
 
 
 def cpu_baseline(inp, target_s=12.0):
@@ -239,8 +242,8 @@ def main():
     px = inp['w'] * inp['h']
     pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if inp['pl'] is not None else 0
 
-    dt, light_ms, tone_ms = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags,
-                                         dist, world, rank)
+    dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
+                      pipelined=(not args.serial and world == 1))
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -250,7 +253,6 @@ def main():
     occ = (inp['sets'][0]['albedo_occ'] >> 24) & 0xFF
     lit_px = int((occ != 0).sum().item())
     abytes, aflops = algorithmic(inp, pairs, args.fused, lit_px)
-    step_light_ms = light_ms                     # event pair around the single launch inside the timed steps
     light_ms = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), args.fused, args.flags)
     tone_burst_ms = 0.0 if args.fused else kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), False, 0, 'tonemap')
     hbm = abytes / (light_ms * 1e-3) / 1e9
@@ -279,8 +281,9 @@ def main():
                                     + (' + ambient' if inp['amb'] else ''),
                            kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
                            buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else f'frame-parallel x{world} + P2P gather to GPU 0'),
-                           tonemap_ms=round(tone_burst_ms, 4), in_step_event_ms=dict(light=round(step_light_ms, 4), tonemap=round(tone_ms, 4)),
-                           kernel_ms_method='burst of back-to-back launches between two HIP events (roofline.ms); in_step_event_ms = event pair around single launches inside the timed steps'),
+                           tonemap_ms=round(tone_burst_ms, 4),
+                           streams=('1 (serial)' if (args.serial or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
+                           kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),
                roofline=primary, roofline_other=other)
 
     if not args.no_extra and world == 1 and args.workload == 'headline':

@@ -21,6 +21,9 @@ for i in range(iters):
     elif case == 'k1_2': lp.light_directional(gbs[k], frame, dl, out=hdrs[k])
     elif case == 'headline': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, out=hdrs[k])
     elif case == 'headline_lds': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, flags=4, out=hdrs[k])
+    elif case == 'hl_noshadow': lp.light_ex(gbs[k], frame, dl, pl, amb, None, out=hdrs[k])
+    elif case == 'hl_nopoints': lp.light_ex(gbs[k], frame, dl, None, amb, sh, flags=4, out=hdrs[k])
+    elif case == 'hl_nodir': lp.light_ex(gbs[k], frame, dl[:0], pl, amb, None, out=hdrs[k])
     elif case == 'points': lp.light_ex(gbs[k], frame, dl[:0], pl, None, None, out=hdrs[k])
     elif case == 'tonemap': lp.tonemap(hdrs[k], 2, out=outs[k])
     else: raise SystemExit('unknown case')
