@@ -47,31 +47,34 @@ def parse():
     ap.add_argument('--sets', type=int, default=3, help='rotating buffer sets (cold-cache protocol)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-extra', action='store_true', help='skip the 4K/1-light HBM-bound side measurement')
+    ap.add_argument('--mode', default='frames', choices=['frames', 'strips'],
+                    help='N > 1: frames = every rank shades whole frames (weak scaling); strips = one frame cut into '
+                         'horizontal strips on 16-row boundaries (strong scaling), both gathered to GPU 0')
     ap.add_argument('--serial', action='store_true', help='one stream: lighting and tonemap back to back (no overlap across frames)')
     ap.add_argument('--fused', action='store_true', help='one kernel: lighting + tonemap -> sRGB8 (20 B/px)')
     ap.add_argument('--flags', type=int, default=0, help='extra MIL_FLAG_* bits (experiments)')
     return ap.parse_args()
 
 
-def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64):
+def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64, rows=None):
     from renderer_amd import sharding
     w, h, n_dir, n_point, shadow_size, ambient = WORKLOADS[wl]
     cam = synth.sweep_camera(w, h) if frame_idx is None else sharding.orbit_camera(frame_idx, n_frames, w, h)
-    gb0 = synth.scene_sweep(w, h, cam, device=device)
+    gb0 = synth.scene_sweep(w, h, cam, device=device, rows=rows)       # rows: this rank's strip (global rows, y_offset set)
     sets = [gb0] + [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in gb0.items()} for _ in range(n_sets - 1)]
     dl = ubo.default_directional_lights()[:n_dir]
     pl = synth.point_light_field(n_point, 0x5EED0003) if n_point else None
     sh = synth.shadow_setup(dl[0, 0:3], shadow_size, device=device) if shadow_size else None
     amb = (0.03, 0.03, 0.03) if ambient else None
     return dict(w=w, h=h, cam=cam, frame=cam.frame_matrix_data(), sets=sets, dl=dl, pl=pl, sh=sh, amb=amb,
-                n_dir=n_dir, n_point=n_point, shadow_size=shadow_size)
+                n_dir=n_dir, n_point=n_point, shadow_size=shadow_size, rows=rows)
 
 
 def algorithmic(inp, pairs, fused, lit_px=None):
     """Per-launch algorithmic bytes and FLOPs of the lighting kernel.  FLOPs are counted for
     LIT pixels only (occlusion > 0): a cleared / background texel is exactly 0 whatever the lights are, and
     the kernel skips it, so counting it would flatter the VALU fraction."""
-    px = inp['w'] * inp['h']
+    px = inp['w'] * inp.get('lh', inp['h'])
     lit = px if lit_px is None else lit_px
     bytes_ = px * (16 + (4 if fused else 16)) + 32 * (inp['n_dir'] + inp['n_point']) + 272
     if inp['shadow_size']:
@@ -86,7 +89,9 @@ def kernel_burst(torch, lighting, lp, inp, n, fused, flags, which='light'):
     command-processor latency; a burst amortises it and agrees with rocprofv3's per-kernel average."""
     dev = lp.device
     n_sets = len(inp['sets'])
-    w, h = inp['w'], inp['h']
+    w, h = inp['w'], inp.get('lh', inp['h'])
+    if h == 0:
+        return float('nan')
     hdr = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
     out = [torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
 
@@ -118,10 +123,16 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
     dev = lp.device
     n_sets = len(inp['sets'])
     w, h = inp['w'], inp['h']
-    hdr = [None if fused else torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
-    out = [torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
-    slots = [[torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(n_sets)] \
-        if (world > 1 and rank == 0) else [None] * n_sets
+    strips = inp.get('rows') is not None
+    bounds = sharding.strip_bounds(h, world) if strips else None
+    lh = (inp['rows'][1] - inp['rows'][0]) if strips else h            # rows this rank shades
+    hdr = [None if fused else torch.empty((lh, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    out = [torch.empty((lh, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
+    if strips:      # rank 0 assembles the whole frame
+        slots = [torch.empty((h, w), dtype=torch.int32, device=dev) if rank == 0 else None for _ in range(n_sets)]
+    else:
+        slots = [[torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(n_sets)] \
+            if (world > 1 and rank == 0) else [None] * n_sets
     pending = [[] for _ in range(n_sets)]
     # Two HIP streams: the tonemap of frame i (HBM-bound) runs beside the lighting of frame i + 1 (VALU-bound).
     main = torch.cuda.current_stream(dev)
@@ -136,7 +147,9 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
             q.wait()
         pending[s] = []
         gb = inp['sets'][s]
-        if fused:
+        if lh == 0:
+            pass                                         # more ranks than 16-row strips: nothing to shade here
+        elif fused:
             lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_SRGB8,
                         flags=flags, out=out[s])
         else:
@@ -151,7 +164,10 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
             used[s] = True
         if world > 1:
             with torch.cuda.stream(post):
-                pending[s] = sharding.gather_frames(out[s], slots[s], dst=0, async_op=True)
+                if strips:
+                    pending[s] = sharding.gather_strips(out[s], bounds, slots[s], dst=0, async_op=True)
+                else:
+                    pending[s] = sharding.gather_frames(out[s], slots[s], dst=0, async_op=True)
 
     def drain():
         for s in range(n_sets):
@@ -238,9 +254,16 @@ def main():
     dev = f'cuda:{local_rank}'
 
     lp = lighting.LightingPass(local_rank, max_point_lights=4096)
-    inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, frame_idx=(rank if world > 1 else None))
+    strips = args.mode == 'strips'
+    if strips:
+        from renderer_amd import sharding
+        y0, y1 = sharding.strip_bounds(WORKLOADS[args.workload][1], world)[rank]
+        inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, rows=(y0, y1))
+        inp['lh'] = y1 - y0
+    else:
+        inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, frame_idx=(rank if world > 1 else None))
     px = inp['w'] * inp['h']
-    pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if inp['pl'] is not None else 0
+    pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if (inp['pl'] is not None and inp.get('lh', 1)) else 0
 
     dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
                       pipelined=(not args.serial and world == 1))
@@ -273,14 +296,15 @@ def main():
     primary, other = (roof_hbm, roof_valu) if roof_hbm['frac'] >= roof_valu['frac'] else (roof_valu, roof_hbm)
 
     res = dict(metric='shaded Mpix/s at 3840x2160, 256 point lights + PCF shadows; % HBM/VALU roofline',
-               value=round(world * args.steps * px / dt / 1e6, 1), unit='Mpix/s', n_gpus=world, steps=args.steps,
-               warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling='weak',
+               value=round((1 if strips else world) * args.steps * px / dt / 1e6, 1), unit='Mpix/s', n_gpus=world, steps=args.steps,
+               warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+               scaling=('strong' if strips else 'weak'),
                vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload=f'{args.workload}: {inp["w"]}x{inp["h"]} Scene A sweep, {inp["n_dir"]} directional '
                                     f'(light 0 PCF {inp["shadow_size"]}^2) + {inp["n_point"]} point lights'
                                     + (' + ambient' if inp['amb'] else ''),
                            kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
-                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else f'frame-parallel x{world} + P2P gather to GPU 0'),
+                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned) + P2P gather to GPU 0' if strips else f'frame-parallel x{world} + P2P gather to GPU 0')),
                            tonemap_ms=round(tone_burst_ms, 4),
                            streams=('1 (serial)' if (args.serial or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),

@@ -51,6 +51,15 @@ def _worker(rank, world, port, out_path):
 
     full = torch.full((H, W, 4), -1.0) if rank == 0 else None
     got = sharding.render_strips(shade, lambda y0, y1: synth.scene_sweep(W, H, cam, rows=(y0, y1)), H, full)
+    # the asynchronous form bench.py --mode strips uses: shade, start the gather, wait later
+    bounds = sharding.strip_bounds(H, world)
+    y0, y1 = bounds[rank]
+    full2 = torch.full((H, W, 4), -1.0) if rank == 0 else None
+    reqs = sharding.gather_strips(shade(synth.scene_sweep(W, H, cam, rows=(y0, y1))), bounds, full2, dst=0, async_op=True)
+    for q in reqs:
+        q.wait()
+    if rank == 0:
+        assert torch.equal(full2, got)
     # frame-parallel: rank r shades frame r of an orbit, rank 0 collects both
     fcam = sharding.orbit_camera(rank, world, W, H)
     g = synth.to_numpy(synth.scene_sweep(W, H, fcam))
