@@ -315,6 +315,37 @@ def test_count_pairs(lp, coracle):
     assert abs(got - pairs) <= max(2, 1e-4 * pairs)
 
 
+def test_fuzz_random_frames_and_degenerate_lights(lp, coracle):
+    """Seeded fuzz: random sizes (tile-edge cases), noise G-buffers, lights with radius 0, huge radius, a light
+    sitting exactly on a pixel's world position (d = 0), zero intensity, more lights than one 64-entry block."""
+    rng = np.random.RandomState(1234)
+    for it in range(6):
+        w, h = int(rng.randint(1, 150)), int(rng.randint(1, 70))
+        n = int(rng.choice([1, 7, 64, 65, 130, 300]))
+        gb, frame, dl, pl, sh = make_scene('noise' if it % 2 else 'sweep', w, h, n_point=n, shadow=64, seed=1000 + it)
+        pl = pl.copy()
+        pl[0, 3] = 0.0                                   # radius 0: never in range
+        if n > 2:
+            pl[1, 3] = 1e4                               # reaches every pixel
+            pl[2, 7] = 0.0                               # zero intensity
+        planes = planes_np(gb)
+        pos = mo.position_from_depth(planes[3].astype(np.float64), w, h, 0, *[mo.unpack_frame_ubo(frame)[k] for k in ('inv_projection', 'inv_view')])
+        if n > 3:
+            pl[3, 0:3] = pos[h // 2, w // 2].astype(np.float32)   # on top of a pixel (up to FP32 rounding of P)
+            pl[3, 3] = 2.0
+        ref = coracle.shade(*planes, frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh))
+        S = lighting.FLAG_STRICT
+        assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=S).cpu().numpy(), ref, f'fuzz {it} strict')
+        assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=S | lighting.FLAG_NO_CULL).cpu().numpy(), ref, f'fuzz {it} strict brute')
+        a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+        b = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f'fuzz {it}: culled != brute force'
+        fin = np.isfinite(ref[..., :3]).all(-1)
+        fa = a.cpu().numpy()
+        tol = 2e-3 + 2e-3 * np.abs(ref[..., :3])         # loose: noise frames contain the ill-conditioned mirror cases
+        assert ((np.abs(fa[..., :3] - ref[..., :3]) > tol).any(-1) & fin).mean() < 0.02
+
+
 # ------------------------------------------------------------------ next row f-1: FXAA
 def test_fxaa_strict_bit_exact_and_fast_tolerance(lp, coracle):
     from test_oracle_kat import fxaa_test_image
