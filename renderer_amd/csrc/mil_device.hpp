@@ -730,9 +730,31 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll
         for (int j = 0; j < 4; j++) i[j] = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
 #pragma unroll
-        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
-#pragma unroll
         for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.albedo + i[j]), (lptr_t)(s_tex + (4 + j) * 64), 4, 0, 0);
+#if !MIL_STRICT
+        // The albedo/occlusion plane goes first: a tile without a lit pixel (sky: half of Scene A) writes its zeros and
+        // never fetches the other three planes (12 of its 16 B/px); lit tiles pay one more LDS-DMA round trip, which
+        // the VALU-bound phase hides (-5 % on the headline frame; MIL_TUNE bit 32 restores the single round).
+        if (!(p.tune & 32u)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; j++) any |= xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
+            if (__builtin_amdgcn_ballot_w64(any) == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (xin && (y0 + 4 * j) <= ylast) store_pixel<FMT>(p, x, y0 + 4 * j, f3{ 0.0f, 0.0f, 0.0f });
+                if (p.tile_counts && lane == 0) p.tile_counts[tyi * p.tiles_x + txi] = 0;
+                if (p.tile_stamps && lane == 0) {
+                    uint32_t *st = p.tile_stamps + 4 * (size_t)(tyi * p.tiles_x + txi);
+                    st[0] = (uint32_t)t_start; st[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); st[2] = 0; st[3] = 0;
+                }
+                return;
+            }
+        }
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.normal + i[j]), (lptr_t)(s_tex + (0 + j) * 64), 4, 0, 0);
 #pragma unroll

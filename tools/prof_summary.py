@@ -28,6 +28,12 @@ for (case, k), cs in sorted(agg.items()):
         v = v[3:] if len(v) > 3 else v
         m[c] = sum(v) / len(v)
         out.append(f'   {c:24s} {m[c]:18.1f}')
+    if 'SQ_ACTIVE_INST_VALU' in m and 'GRBM_GUI_ACTIVE' in m and 'SQ_INSTS_VALU' in m:
+        # SQ counters are in quad-cycles summed over the chip; GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+        cyc = m['GRBM_GUI_ACTIVE'] / 8.0
+        out.append(f'   -> kernel {cyc / 2.4e3:.1f} us at 2.4 GHz; VALU pipe busy {m["SQ_ACTIVE_INST_VALU"] * 4 / (cyc * 1024) * 100:.0f} % of SIMD-cycles; '
+                   f'{m["SQ_ACTIVE_INST_VALU"] * 4 / m["SQ_INSTS_VALU"]:.2f} cycles per VALU wave-instruction; '
+                   f'{m["SQ_INSTS_VALU"] / 1e6:.1f} M VALU wave-instructions')
     if 'FETCH_SIZE' in m and 'WRITE_SIZE' in m:
         # MI355X_MICROARCH.md, HBM: FETCH_SIZE (KiB) reads exactly half of a coalesced stream's bytes on
         # gfx950 -> x2; WRITE_SIZE (KiB) is exact for 16-B-per-lane streaming stores.
