@@ -50,7 +50,9 @@ def parse():
     ap.add_argument('--mode', default='frames', choices=['frames', 'strips'],
                     help='N > 1: frames = every rank shades whole frames (weak scaling); strips = one frame cut into '
                          'horizontal strips on 16-row boundaries (strong scaling), both gathered to GPU 0')
-    ap.add_argument('--serial', action='store_true', help='one stream: lighting and tonemap back to back (no overlap across frames)')
+    ap.add_argument('--pipelined', action='store_true',
+                    help='N = 1: tonemap of frame i on a second stream beside the lighting of frame i + 1 (+3 %%; off by default so '
+                         'that per-kernel durations under rocprofv3 are those of kernels running alone)')
     ap.add_argument('--fused', action='store_true', help='one kernel: lighting + tonemap -> sRGB8 (20 B/px)')
     ap.add_argument('--flags', type=int, default=0, help='extra MIL_FLAG_* bits (experiments)')
     return ap.parse_args()
@@ -266,7 +268,7 @@ def main():
     pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if (inp['pl'] is not None and inp.get('lh', 1)) else 0
 
     dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
-                      pipelined=(not args.serial and world == 1))
+                      pipelined=(args.pipelined and world == 1))
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -306,7 +308,7 @@ def main():
                            kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
                            buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned) + P2P gather to GPU 0' if strips else f'frame-parallel x{world} + P2P gather to GPU 0')),
                            tonemap_ms=round(tone_burst_ms, 4),
-                           streams=('1 (serial)' if (args.serial or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
+                           streams=('1 (serial)' if (not args.pipelined or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),
                roofline=primary, roofline_other=other)
 
