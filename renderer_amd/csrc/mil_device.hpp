@@ -1130,6 +1130,72 @@ __global__ __launch_bounds__(256) void k_fxaa(const FxaaParams p)
                                 p.out + (size_t)yy * p.out_pitch + x);
 }
 
+#if !MIL_STRICT
+// Fast FXAA: each lane owns ONE column and TWO output rows (y, y + 1); it decodes the four texels of its column
+// in rows y - 1 .. y + 2 once, and the diagonal neighbours' lumas come from lanes l - 1 / l + 1 by DPP wave
+// shifts instead of four more loads + decodes each.  Lanes 0 and 63 are halo lanes (columns x0 - 1, x0 + 62), so
+// a wave produces 62 columns.  Per-pixel arithmetic is float2 (packed).  Same texel picks as k_fxaa.
+template <int CTRL> DEV float wave_shift(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(256) void k_fxaa2(const FxaaParams p)
+{
+    const int lane = (int)threadIdx.x;
+    const int col = (int)(blockIdx.x * 62) + lane - 1;                 // may be -1 or >= width: clamp to edge
+    const uint32_t yy = (blockIdx.y * 4 + threadIdx.y) * 2;             // first of the lane's two rows, strip-local
+    if (yy >= p.row_count) return;                                      // whole wave
+    const int y = (int)(p.row_begin + yy);
+    const int xc = min(max(col, 0), (int)p.width - 1), H1 = (int)p.height - 1;
+    f3 c[4];
+    float L[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        c[r] = fxaa_decode(p.ldr[(size_t)min(max(y - 1 + r, 0), H1) * p.ldr_pitch + xc]);
+        L[r] = fxaa_luma(c[r]);
+    }
+    float Lw[4], Le[4];                                                  // the same rows, one column to the west / east
+#pragma unroll
+    for (int r = 0; r < 4; r++) { Lw[r] = wave_shift<0x138>(L[r]); Le[r] = wave_shift<0x130>(L[r]); }   // wave_shr:1 / wave_shl:1
+    const float KRED = 0.03125f, REDUCE_MIN = 0.0078125f, SPAN = 8.0f;
+    const float K1 = (float)(1.0 / 3.0 - 0.5), K2 = (float)(2.0 / 3.0 - 0.5);
+    const v2f lNW = { Lw[0], Lw[1] }, lNE = { Le[0], Le[1] }, lSW = { Lw[2], Lw[3] }, lSE = { Le[2], Le[3] }, lM = { L[1], L[2] };
+    const v2f lmin = { fminf(lM.x, fminf(fminf(lNW.x, lNE.x), fminf(lSW.x, lSE.x))), fminf(lM.y, fminf(fminf(lNW.y, lNE.y), fminf(lSW.y, lSE.y))) };
+    const v2f lmax = { fmaxf(lM.x, fmaxf(fmaxf(lNW.x, lNE.x), fmaxf(lSW.x, lSE.x))), fmaxf(lM.y, fmaxf(fmaxf(lNW.y, lNE.y), fmaxf(lSW.y, lSE.y))) };
+    v2f dx = (lSW + lSE) - (lNW + lNE), dy = (lNW + lSW) - (lNE + lSE);
+    const v2f red = max_((lNW + lNE + lSW + lSE) * KRED, (v2f)(REDUCE_MIN));
+    const v2f rcpmin = rcp_(v2f{ fminf(fabsf(dx.x), fabsf(dy.x)), fminf(fabsf(dx.y), fabsf(dy.y)) } + red);
+    dx = med3_(dx * rcpmin, -SPAN, SPAN);
+    dy = med3_(dy * rcpmin, -SPAN, SPAN);
+    const bool live = lane >= 1 && lane <= 62 && col < (int)p.width;
+    f3 o[2] = { c[1], c[2] };
+    const bool edge0 = fmaxf(fabsf(dx.x), fabsf(dy.x)) > 0.99f, edge1 = fmaxf(fabsf(dx.y), fabsf(dy.y)) > 0.99f;
+    if (__builtin_amdgcn_ballot_w64(live && (edge0 || edge1)) != 0) {
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float ddx = e ? dx.y : dx.x, ddy = e ? dy.y : dy.x;
+            const float fx = (float)col + 0.5f, fy = (float)(y + e) + 0.5f;
+            auto tap = [&](float k) {
+                return fxaa_texel(p, (int)floorf(__builtin_fmaf(ddx, k, fx)), (int)floorf(__builtin_fmaf(ddy, k, fy)));
+            };
+            const f3 t0 = tap(K1), t1 = tap(K2), t2 = tap(-0.5f), t3 = tap(0.5f);
+            const f3 a = { 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
+            const f3 b = { __builtin_fmaf(0.25f, t2.x + t3.x, a.x * 0.5f), __builtin_fmaf(0.25f, t2.y + t3.y, a.y * 0.5f),
+                           __builtin_fmaf(0.25f, t2.z + t3.z, a.z * 0.5f) };
+            const float lB = fxaa_luma(b), mn = e ? lmin.y : lmin.x, mx = e ? lmax.y : lmax.x;
+            o[e] = (lB < mn || lB > mx) ? a : b;
+        }
+    }
+    if (!live) return;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        if (yy + e >= p.row_count) break;
+        __builtin_nontemporal_store(srgb8_direct(sat(o[e].z)) | (srgb8_direct(sat(o[e].y)) << 8) | (srgb8_direct(sat(o[e].x)) << 16) | 0xFF000000u,
+                                    p.out + (size_t)(yy + e) * p.out_pitch + col);
+    }
+}
+#endif
+
 // ---------------------------------------------------------------------------------
 // K6 (next row f-4): Hosek-Wilkie sky subpass as a screen-space pass, renderer/shaders/sky_hosek_frag.glsl:28-60
 // (draw render/mod.rs:221-226; depth test LessOrEqual at z = w - 1e-5, render/hosek/mod.rs:58-64,
@@ -1267,8 +1333,13 @@ void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
 }
 void launch_fxaa(const FxaaParams &p, hipStream_t s)
 {
+#if MIL_STRICT
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.row_count + 3) / 4);
     hipLaunchKernelGGL(k_fxaa, grid, block, 0, s, p);
+#else
+    dim3 block(64, 4), grid((p.width + 61) / 62, (p.row_count + 7) / 8);
+    hipLaunchKernelGGL(k_fxaa2, grid, block, 0, s, p);
+#endif
 }
 void launch_sky(const SkyParams &p, hipStream_t s)
 {
