@@ -775,9 +775,22 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         lit4[j] = xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
     // a tile without a lit pixel (sky) has an empty box: no positions, no reductions, no culling
     if ((p.n_point > 0 || stage) && __builtin_amdgcn_ballot_w64(lit4[0] || lit4[1] || lit4[2] || lit4[3]) != 0) {
+#if !MIL_STRICT
+        f3 P4[4];    // the same packed evaluation as the shading passes (rows j, j + 1 together): identical positions
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+            const PosT<v2f> q2 = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(y0 + 4 * jj + p.y_offset), (float)(y0 + 4 * jj + 4 + p.y_offset) },
+                                                       v2f{ __uint_as_float(s_tex[(12 + jj) * 64 + lane]), __uint_as_float(s_tex[(13 + jj) * 64 + lane]) });
+            P4[jj] = f3{ q2.P.x.x, q2.P.y.x, q2.P.z.x }; P4[jj + 1] = f3{ q2.P.x.y, q2.P.y.y, q2.P.z.y };
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
+#if MIL_STRICT
             const f3 P = pixel_position(p, x, y0 + 4 * j, __uint_as_float(s_tex[(12 + j) * 64 + lane])).P;
+#else
+            const f3 P = P4[j];
+#endif
             const bool lit = lit4[j];
             if (lit) {
                 lo.x = fminf(lo.x, P.x); lo.y = fminf(lo.y, P.y); lo.z = fminf(lo.z, P.z);
