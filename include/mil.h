@@ -187,6 +187,28 @@ int mil_light_ex(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_dat
                  const mil_extras *extras, void *out, uint32_t out_pitch_px, mil_out_format fmt,
                  uint32_t flags, void *stream);
 
+/* The hdr-writing subpasses that follow the lighting draw inside the reference's one render pass
+ * (render/pbr/mod.rs:409-440), for mil_shade_frame.  NULL members switch a subpass off. */
+typedef struct mil_frame_passes {
+    const mil_hosek_wilkie_params *sky; /* HOST; sky subpass, render/mod.rs:221-226 (as mil_sky_hosek) */
+    const void *accum;                  /* DEVICE R16G16B16A16_SFLOAT; resolve subpass, render/mod.rs:282-294 */
+    const void *reveal;                 /* DEVICE R16_SFLOAT (both or neither) */
+    uint32_t accum_pitch_px, reveal_pitch_px;
+} mil_frame_passes;
+
+/* Replaces the subpass chain lighting -> sky -> transparency resolve -> tonemap of Frame::build
+ * (render/mod.rs:201-216, 221-226, 282-294, 297-309) with ONE launch: per pixel, the result of mil_light_ex is
+ * replaced by the sky radiance where the depth is still the clear value, blended with the resolved transparency,
+ * and encoded as `fmt`, all in registers.  The reference keeps hdr as a transient attachment of one render pass
+ * (render/pbr/mod.rs:76-95: it need never reach memory); here it does not exist at all unless
+ * fmt = MIL_OUT_HDR_RGBA32F asks for it.  Result = mil_light_ex(HDR) + mil_sky_hosek + mil_transparency_resolve
+ * + mil_tonemap(fmt) on the same inputs.  The forward accumulate pass that fills accum / reveal
+ * (render/mod.rs:232-280) reads only depth and must have run before this call.  extras, passes: may be NULL. */
+int mil_shade_frame(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                    const mil_directional_light *lights, const mil_push_constants *push,
+                    const mil_extras *extras, const mil_frame_passes *passes, void *out, uint32_t out_pitch_px,
+                    mil_out_format fmt, uint32_t flags, void *stream);
+
 /* Diagnostics for the roofline accounting: number of (pixel, point light) pairs
  * with d^2 < r^2 and occlusion > 0, by brute force (independent of the culling).
  * count: DEVICE uint64, overwritten. */

@@ -366,11 +366,13 @@ int mil_sync(mil_ctx *c, void *stream)
     return MIL_OK;
 }
 
-int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+// mil_light_ex and mil_shade_frame: the same launch, the second with the later subpasses folded into the store
+static int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
                  const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
-                 void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
+                 const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
 {
     if (!c || !frame || !out) return MIL_ERR_BAD_ARG;
+    if (passes && ((passes->accum != nullptr) != (passes->reveal != nullptr))) return MIL_ERR_BAD_ARG;
     int rc = check_gbuffer(gb, push);
     if (rc) return rc;
     if (out_pitch_px < gb->width || (unsigned)fmt > MIL_OUT_SRGB8_BGRA_VIA_LDR) return MIL_ERR_BAD_ARG;
@@ -406,6 +408,18 @@ int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     p.out_pitch = out_pitch_px;
     p.lut11 = c->lut;
     p.lut10 = c->lut + LUT11_N;
+    const bool whole = passes != nullptr;
+    if (whole) {
+        if (passes->accum && (passes->accum_pitch_px < gb->width || passes->reveal_pitch_px < gb->width)) return MIL_ERR_BAD_ARG;
+        if (passes->sky) {
+            p.has_sky = 1;
+            static_assert(sizeof(p.hw) == sizeof(mil_hosek_wilkie_params), "HosekWilkieParams is 11 x vec4");
+            memcpy(p.hw, passes->sky, sizeof(p.hw));
+        }
+        p.accum = (const uint16_t *)passes->accum; p.reveal = (const uint16_t *)passes->reveal;
+        p.accum_pitch = passes->accum_pitch_px; p.reveal_pitch = passes->reveal_pitch_px;
+        p.resolve_dma = p.accum && !(gb->width & 1u) && !(p.reveal_pitch & 1u) && !((uintptr_t)p.reveal & 3u) && !((uintptr_t)p.accum & 3u) && !(c->tune & 128u);
+    }
 
     const bool strict = (flags & MIL_FLAG_STRICT) != 0;
     const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
@@ -413,13 +427,29 @@ int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
         order_rows(p, frame, ex ? ex->point_lights : nullptr, n_point);
         p.tile_counts = c->tile_counts;
         p.tile_stamps = c->tile_stamps;
-        if (strict) mil::strict::launch_tiled((int)fmt, p, s);
-        else mil::fast::launch_tiled((int)fmt, p, s);
+        if (strict) mil::strict::launch_tiled((int)fmt, p, whole, s);
+        else mil::fast::launch_tiled((int)fmt, p, whole, s);
     } else {
-        if (strict) mil::strict::launch_stream((int)fmt, p, s);
-        else mil::fast::launch_stream((int)fmt, p, s);
+        if (strict) mil::strict::launch_stream((int)fmt, p, whole, s);
+        else mil::fast::launch_stream((int)fmt, p, whole, s);
     }
     return finish(c, slot, s);
+}
+
+int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                 const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                 void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
+{
+    return shade(c, gb, frame, lights, push, ex, nullptr, out, out_pitch_px, fmt, flags, stream);
+}
+
+int mil_shade_frame(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                    const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                    const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt,
+                    uint32_t flags, void *stream)
+{
+    static const mil_frame_passes none = {};
+    return shade(c, gb, frame, lights, push, ex, passes ? passes : &none, out, out_pitch_px, fmt, flags, stream);
 }
 
 int mil_light_directional(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,

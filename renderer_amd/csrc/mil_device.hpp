@@ -483,6 +483,89 @@ DEV float pcf_direct(const ShadowTap &t, const ShadeParams &p)
 }
 
 // ---------------------------------------------------------------------------------
+// Per-pixel math of the sky (K6) and transparency-resolve (K7) subpasses, shared by their own kernels and by
+// the whole-frame launch (emit_pixel below), so that the fused frame equals the chain of separate calls.
+// ---------------------------------------------------------------------------------
+#define MIL_SKY_DEPTH 0.99999994f   // largest float below 1: LessOrEqual at z = w - 1e-5 passes only texels at the clear depth
+#if !MIL_STRICT
+// acos on [0, 1] (cos(gamma) is clamped to >= 0.001): sqrt(1 - x) * P7(x), Abramowitz & Stegun 4.4.46, |error| <= 2e-8 + FP32
+// rounding -- a dozen instructions instead of the library routine's forty
+DEV float acos01(float x)
+{
+    float q = -0.0012624911f;
+    q = __builtin_fmaf(q, x, 0.0066700901f); q = __builtin_fmaf(q, x, -0.0170881256f); q = __builtin_fmaf(q, x, 0.0308918810f);
+    q = __builtin_fmaf(q, x, -0.0501743046f); q = __builtin_fmaf(q, x, 0.0889789874f); q = __builtin_fmaf(q, x, -0.2145988016f);
+    q = __builtin_fmaf(q, x, 1.5707963050f);
+    return sqrt_(1.0f - x) * q;
+}
+#endif
+template <typename PRM>
+DEV void sky_radiance(const PRM &p, uint32_t x, uint32_t y, float d, float r3[3])   // sky_hosek_frag.glsl:28-60
+{
+    const float *A = p.hw[0], *B = p.hw[1], *C = p.hw[2], *D = p.hw[3], *E = p.hw[4], *F = p.hw[5], *G = p.hw[6], *H = p.hw[7],
+                *I = p.hw[8], *Z = p.hw[9], *sun = p.hw[10];
+#if MIL_STRICT
+    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
+    float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
+    float vx = mrow(p.inv_proj, 0, px, py, d, 1.0f), vy = mrow(p.inv_proj, 1, px, py, d, 1.0f);
+    float vz = mrow(p.inv_proj, 2, px, py, d, 1.0f), vw = mrow(p.inv_proj, 3, px, py, d, 1.0f);
+    vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
+    f3 P = { mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
+    f3 vd = normalize3(f3{ P.x - p.cam[0], P.y - p.cam[1], P.z - p.cam[2] });                    // :56-58
+    const float cg = fmaxf(0.001f, dot3(f3{ sun[0], sun[1], sun[2] }, vd));                      // :46
+    const float ct = fmaxf(0.001f, (vd.x * 0.0f + vd.y * 1.0f) + vd.z * 0.0f);                   // :47
+    const float gamma = (float)acos((double)cg);                                                 // :49 (exp / pow / acos in double, as the oracle)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float chi = (1.0f + cg * cg) / (float)pow((double)((1.0f + H[c] * H[c]) - (2.0f * H[c]) * cg), 1.5);   // :39
+        const float left = 1.0f + A[c] * (float)exp((double)(B[c] / (ct + 0.01f)));              // :41
+        const float right = (((C[c] + D[c] * (float)exp((double)(E[c] * gamma))) + (F[c] * cg) * cg) + G[c] * chi) + I[c] * sqrtf(ct);
+        r3[c] = ((left * right) * Z[c]) * 0.05f;                                                 // :51, :58
+    }
+#else
+    const float xf = (float)x, yf = (float)(y + p.y_offset);
+    const float *m = p.pos_m;
+    // direction only: the w divide of PositionFromDepth is a positive scale the normalisation removes
+    f3 v = { __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, __builtin_fmaf(m[2], d, m[3]))),
+             __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, __builtin_fmaf(m[6], d, m[7]))),
+             __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, __builtin_fmaf(m[10], d, m[11]))) };
+    const float vw = __builtin_fmaf(m[12], xf, __builtin_fmaf(m[13], yf, __builtin_fmaf(m[14], d, m[15])));
+    const float rn = rsq_(dot3(v, v)) * (vw < 0.0f ? -1.0f : 1.0f);
+    const f3 vd = { v.x * rn, v.y * rn, v.z * rn };
+    const float cg = fmaxf(0.001f, dot3(f3{ sun[0], sun[1], sun[2] }, vd));
+    const float ct = fmaxf(0.001f, vd.y);
+    const float gamma = acos01(cg);
+    const float cg2 = cg * cg, sct = sqrt_(ct), ict = rcp_(ct + 0.01f);
+    const float LOG2E = 1.4426950408889634f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float t = __builtin_fmaf(-2.0f * H[c], cg, __builtin_fmaf(H[c], H[c], 1.0f));       // 1 + H^2 - 2 H cos(gamma)
+        const float chi = (1.0f + cg2) * rsq_(t) * rcp_(t);                                       // t^-1.5
+        const float left = __builtin_fmaf(A[c], __builtin_amdgcn_exp2f(B[c] * ict * LOG2E), 1.0f);
+        const float right = __builtin_fmaf(I[c], sct, __builtin_fmaf(G[c], chi, __builtin_fmaf(F[c], cg2,
+                            __builtin_fmaf(D[c], __builtin_amdgcn_exp2f(E[c] * gamma * LOG2E), C[c]))));
+        r3[c] = left * right * (Z[c] * 0.05f);
+    }
+#endif
+}
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+DEV bool resolve_untouched(h4 a, float r)     // nothing transparent here: 0 * 0 + hdr * 1 = hdr exactly
+{
+    return r == 1.0f && (float)a.x == 0.0f && (float)a.y == 0.0f && (float)a.z == 0.0f;
+}
+DEV v4f resolve_blend(h4 a, float r, v4f h)    // fs_mcguire13_resolve.glsl:8-13 + blend mcguire13/mod.rs:108-120
+{
+    const float ar = (float)a.x, ag = (float)a.y, ab = (float)a.z, aa = (float)a.w;
+    const float den = fminf(5e4f, fmaxf(1e-4f, aa)), om = 1.0f - r;
+#if MIL_STRICT
+    return v4f{ (ar / den) * om + h.x * r, (ag / den) * om + h.y * r, (ab / den) * om + h.z * r, r * om + h.w * r };
+#else
+    const float k = rcp_(den) * om;
+    return v4f{ __builtin_fmaf(ar, k, h.x * r), __builtin_fmaf(ag, k, h.y * r), __builtin_fmaf(ab, k, h.z * r), __builtin_fmaf(r, om, h.w * r) };
+#endif
+}
+
+// ---------------------------------------------------------------------------------
 // output encode (fs_tonemap.glsl:23-27 + attachment formats)
 // ---------------------------------------------------------------------------------
 DEV uint32_t ufloat_enc(float x, int mbits)
@@ -509,14 +592,54 @@ DEV uint32_t encode_ldr(float r, float g, float b, const uint8_t *lut11, const u
     return (uint32_t)lut10[cb] | ((uint32_t)lut11[cg] << 8) | ((uint32_t)lut11[cr] << 16) | 0xFF000000u;
 }
 template <int FMT>
-DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res)
+DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res, float alpha = 1.0f)
 {
     size_t o = (size_t)y * p.out_pitch + x;
     if (FMT == FMT_HDR) {
-        __builtin_nontemporal_store(v4f{ res.x, res.y, res.z, 1.0f }, (v4f *)p.out + o);   // fs_deferred_lighting.glsl:66
+        __builtin_nontemporal_store(v4f{ res.x, res.y, res.z, alpha }, (v4f *)p.out + o);   // fs_deferred_lighting.glsl:66
     } else {
         __builtin_nontemporal_store(encode_ldr<FMT>(res.x, res.y, res.z, p.lut11, p.lut10), (uint32_t *)p.out + o);
     }
+}
+// Whole-frame launch (FRAME, mil_shade_frame): what the later hdr-writing subpasses of the reference's render pass do
+// to this pixel happens in registers before the one store - sky where the depth is still the clear value
+// (render/mod.rs:221-226), then the transparency resolve blend (render/mod.rs:282-294), then the tonemap/pack of FMT
+// (render/mod.rs:297-309).  hdr is a transient attachment in the reference (pbr/mod.rs:76-95); here it never exists.
+template <int FMT, bool FRAME>
+DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f3 res, const uint32_t *tile = nullptr)
+{
+    if (!FRAME) { store_pixel<FMT>(p, x, y, res); return; }
+    v4f h = { res.x, res.y, res.z, 1.0f };
+    if (p.has_sky) {
+        const bool sky = depth >= MIL_SKY_DEPTH;
+        if (__builtin_amdgcn_ballot_w64(sky) != 0) {
+            float r3[3];
+            sky_radiance(p, x, y, depth, r3);
+            if (sky) h = v4f{ r3[0], r3[1], r3[2], 1.0f };
+        }
+    }
+    if (p.accum) {
+        h4 a;
+        float r;
+        if (tile) {             // k_tiled staged the tile's accum / revealage texels in LDS (LDS-DMA, with the G-buffer planes)
+            const uint32_t c = x & 15u, row = y & 15u;
+            typedef uint32_t u2_t __attribute__((ext_vector_type(2)));
+            const u2_t aw = *(const u2_t *)(tile + 2 * (row * 16 + c));
+            const uint32_t rw = tile[512 + row * 8 + (c >> 1)];
+            union { u2_t u; h4 h; } cv; cv.u = aw; a = cv.h;
+            union { unsigned short s; _Float16 h; } rv; rv.s = (unsigned short)(rw >> (16 * (c & 1u)));
+            r = (float)rv.h;
+        } else {
+            a = __builtin_nontemporal_load((const h4 *)p.accum + (size_t)y * p.accum_pitch + x);
+            r = (float)__builtin_nontemporal_load((const _Float16 *)p.reveal + (size_t)y * p.reveal_pitch + x);
+        }
+#if MIL_STRICT
+        h = resolve_blend(a, r, h);
+#else
+        if (__builtin_amdgcn_ballot_w64(!resolve_untouched(a, r)) != 0) h = resolve_blend(a, r, h);
+#endif
+    }
+    store_pixel<FMT>(p, x, y, f3{ h.x, h.y, h.z }, h.w);
 }
 
 // ---------------------------------------------------------------------------------
@@ -525,7 +648,7 @@ DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res)
 // rows, issues all 16 loads first and then shades the four pixels one after the other.
 // Handles directional lights, shadow by direct taps, brute-force point lights, ambient.
 // ---------------------------------------------------------------------------------
-template <int FMT, bool EXT>
+template <int FMT, bool EXT, bool FRAME>
 DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth, DirRec d0)
 {
     Px q;
@@ -544,12 +667,12 @@ DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, uint32
         for (uint32_t l = 0; l < p.n_point; l++) add_point(q, point_rec_a(p, l), point_rec_b(p, l), res);
         if (p.has_ambient) add_ambient(q, p, u2, res);
     }
-    store_pixel<FMT>(p, x, y, res);
+    emit_pixel<FMT, FRAME>(p, x, y, depth, res);
 }
 
 template <typename T> DEV T sel4(uint32_t j, T a, T b, T c, T d) { return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)); }
 
-template <int FMT, int NPX, bool EXT>
+template <int FMT, int NPX, bool EXT, bool FRAME>
 __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
 {
     // Coordinates are clamped for the loads instead of branched around: the texel loads are the
@@ -567,11 +690,11 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
         // extensions on: a wave whose 64 pixels all have occlusion 0 (cleared G-buffer) writes its exact zeros
         // and skips shadow taps, point lights and BRDF (the same early-out as k_tiled)
         if (EXT && __builtin_amdgcn_ballot_w64((u2 >> 24) != 0) == 0) {
-            store_pixel<FMT>(p, x, y, f3{ 0.0f, 0.0f, 0.0f });
+            emit_pixel<FMT, FRAME>(p, x, y, depth, f3{ 0.0f, 0.0f, 0.0f });
             return;
         }
 #endif
-        shade_stream_pixel<FMT, EXT>(p, x, y, u1, u2, u3, depth, d0);
+        shade_stream_pixel<FMT, EXT, FRAME>(p, x, y, u1, u2, u3, depth, d0);
         return;
     }
     const uint32_t y0 = blockIdx.y * 16 + threadIdx.y;     // this lane: rows y0, y0+4, y0+8, y0+12
@@ -589,7 +712,7 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t y = y0 + 4 * j;
         if (y > ylast) break;
-        shade_stream_pixel<FMT, EXT>(p, x, y, sel4(j, u1[0], u1[1], u1[2], u1[3]), sel4(j, u2[0], u2[1], u2[2], u2[3]),
+        shade_stream_pixel<FMT, EXT, FRAME>(p, x, y, sel4(j, u1[0], u1[1], u1[2], u1[3]), sel4(j, u2[0], u2[1], u2[2], u2[3]),
                                      sel4(j, u3[0], u3[1], u3[2], u3[3]), sel4(j, dz[0], dz[1], dz[2], dz[3]), d0);
     }
 }
@@ -663,15 +786,16 @@ DEV float box_d2(v4f a, f3 lo, f3 hi)
 }
 
 // Per-wave LDS carve of k_tiled (bytes), shared by the launcher and the kernel.
-struct TiledLds { uint32_t list, stash, shadow, per_wave; };
-static __host__ __device__ __forceinline__ TiledLds tiled_lds(uint32_t n_point, bool stage)
+struct TiledLds { uint32_t list, stash, shadow, resolve, per_wave; };
+static __host__ __device__ __forceinline__ TiledLds tiled_lds(uint32_t n_point, bool stage, bool resolve)
 {
     TiledLds l;
     const uint32_t cap = n_point < (uint32_t)CHUNK ? ((n_point + 63u) & ~63u) : (uint32_t)CHUNK;   // list entries (u16)
     l.list = 4096u;                                                   // after the 4 x 4 x 64 texel dwords
     l.stash = l.list + ((cap * 2u + 15u) & ~15u);
     l.shadow = l.stash + (n_point > (uint32_t)CHUNK ? 768u * 4u : 0u);
-    l.per_wave = l.shadow + (stage ? (uint32_t)SH_CAP * 4u : 0u);
+    l.resolve = l.shadow + (stage ? (uint32_t)SH_CAP * 4u : 0u);
+    l.per_wave = l.resolve + (resolve ? 2560u : 0u);                  // whole frame: 256 accum texels (8 B) + 256 revealage (2 B)
     return l;
 }
 
@@ -693,7 +817,7 @@ DEV const ShadeParams &kernarg_params()
     return *(const ShadeParams *)pp;
 }
 
-template <int FMT>
+template <int FMT, bool FRAME>
 __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 {
     const ShadeParams &p = kernarg_params();
@@ -704,12 +828,16 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const uint32_t wpb = blockDim.x >> 6;               // waves (= tiles) per workgroup
     const bool do_shadow = p.has_shadow && p.n_dir > 0;
     const bool stage = do_shadow && p.shadow_lds;
-    const TiledLds L = tiled_lds(p.n_point, stage);
+    // whole frame with a resolve: the tile's accum / revealage texels ride the LDS-DMA with the G-buffer planes, so their
+    // latency is not exposed at the store (dword granularity: the host sets resolve_dma when pitches / width allow it)
+    const bool rdma = FRAME && p.accum && p.resolve_dma;
+    const TiledLds L = tiled_lds(p.n_point, stage, rdma);
     unsigned char *s_wave = s_raw + wv * L.per_wave;
     uint32_t *s_tex = (uint32_t *)s_wave;               // [plane: normal, albedo, rm, depth][j][lane]
     uint16_t *s_list = (uint16_t *)(s_wave + L.list);
     float *s_res = (float *)(s_wave + L.stash);
     float *s_shadow = (float *)(s_wave + L.shadow);
+    const uint32_t *s_resolve = rdma ? (const uint32_t *)(s_wave + L.resolve) : nullptr;
 
     // Workgroup -> tile: consecutive workgroups (dealt round-robin over the XCDs by the dispatcher) walk along one
     // tile row (a workgroup reads whole 256-byte row segments).  The ROWS are visited in the order the host
@@ -731,11 +859,31 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         for (int j = 0; j < 4; j++) i[j] = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
 #pragma unroll
         for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.albedo + i[j]), (lptr_t)(s_tex + (4 + j) * 64), 4, 0, 0);
+        if (rdma) {
+            uint32_t *dst = (uint32_t *)(s_wave + L.resolve);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {       // accum: 16 rows x 32 dwords, two rows per step
+                const uint32_t row = 2 * k + (lane >> 5), d = lane & 31u;
+                const size_t t = (size_t)min(tyi * TILE + row, ylast) * p.accum_pitch + min(txi * TILE + (d >> 1), p.width - 1);
+                __builtin_amdgcn_global_load_lds((gptr_t)((const uint32_t *)p.accum + 2 * t + (d & 1u)), (lptr_t)(dst + k * 64), 4, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {       // revealage: 16 rows x 8 dwords (two texels each; width and pitch are even here)
+                const uint32_t row = 8 * k + (lane >> 3), d = lane & 7u;
+                const size_t t = (size_t)min(tyi * TILE + row, ylast) * p.reveal_pitch + min(txi * TILE + 2 * d, p.width - 2);
+                __builtin_amdgcn_global_load_lds((gptr_t)(p.reveal + t), (lptr_t)(dst + 512 + k * 64), 4, 0, 0);
+            }
+        }
 #if !MIL_STRICT
         // The albedo/occlusion plane goes first: a tile without a lit pixel (sky: half of Scene A) writes its zeros and
         // never fetches the other three planes (12 of its 16 B/px); lit tiles pay one more LDS-DMA round trip, which
         // the VALU-bound phase hides (-5 % on the headline frame; MIL_TUNE bit 32 restores the single round).
         if (!(p.tune & 32u)) {
+            const bool early_depth = FRAME && p.has_sky;     // a sky texel is told by its depth
+            if (early_depth) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bool any = false;
 #pragma unroll
@@ -743,7 +891,8 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             if (__builtin_amdgcn_ballot_w64(any) == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (xin && (y0 + 4 * j) <= ylast) store_pixel<FMT>(p, x, y0 + 4 * j, f3{ 0.0f, 0.0f, 0.0f });
+                    if (xin && (y0 + 4 * j) <= ylast)
+                        emit_pixel<FMT, FRAME>(p, x, y0 + 4 * j, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
                 if (p.tile_counts && lane == 0) p.tile_counts[tyi * p.tiles_x + txi] = 0;
                 if (p.tile_stamps && lane == 0) {
                     uint32_t *st = p.tile_stamps + 4 * (size_t)(tyi * p.tiles_x + txi);
@@ -752,9 +901,12 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 return;
             }
         }
+        if (!(FRAME && p.has_sky) || (p.tune & 32u))
 #endif
+        {
 #pragma unroll
-        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
+            for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.normal + i[j]), (lptr_t)(s_tex + (0 + j) * 64), 4, 0, 0);
 #pragma unroll
@@ -921,7 +1073,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             }
             if (ch + 1 == n_chunks) {
                 if (p.has_ambient) add_ambient(q, p, w2, r);
-                if (inbj) store_pixel<FMT>(p, x, y, r);
+                if (inbj) emit_pixel<FMT, FRAME>(p, x, y, depth, r, s_resolve);
             } else {
                 s_res[j * 64 + lane] = r.x; s_res[256 + j * 64 + lane] = r.y; s_res[512 + j * 64 + lane] = r.z;
             }
@@ -943,8 +1095,8 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             // fs_deferred_lighting.glsl:63 and of the extensions: the pixel is exactly 0.  When none of the
             // pass's 128 pixels is lit the wave writes the zeros and skips the shading altogether.
             if (__builtin_amdgcn_ballot_w64(litA || litB) == 0) {
-                if (last && inA) store_pixel<FMT>(p, x, ya, f3{ 0.0f, 0.0f, 0.0f });
-                if (last && inB) store_pixel<FMT>(p, x, yb, f3{ 0.0f, 0.0f, 0.0f });
+                if (last && inA) emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+                if (last && inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
                 continue;
             }
             Px2 q;
@@ -990,8 +1142,8 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                     r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
                     r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
                 }
-                if (inA) store_pixel<FMT>(p, x, ya, f3{ r.x.x, r.y.x, r.z.x });
-                if (inB) store_pixel<FMT>(p, x, yb, f3{ r.x.y, r.y.y, r.z.y });
+                if (inA) emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ r.x.x, r.y.x, r.z.x }, s_resolve);
+                if (inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ r.x.y, r.y.y, r.z.y }, s_resolve);
             } else {
                 s_res[ja * 64 + lane] = r.x.x; s_res[(ja + 1) * 64 + lane] = r.x.y;
                 s_res[256 + ja * 64 + lane] = r.y.x; s_res[256 + (ja + 1) * 64 + lane] = r.y.y;
@@ -1221,54 +1373,10 @@ __global__ __launch_bounds__(256) void k_sky(const SkyParams p)
     const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= p.width || y >= p.height) return;
     const float d = p.depth[(size_t)y * p.depth_pitch + x];
-    const bool sky = d >= 0.99999994f;
+    const bool sky = d >= MIL_SKY_DEPTH;
     if (__builtin_amdgcn_ballot_w64(sky) == 0) return;
-    const float *A = p.hw[0], *B = p.hw[1], *C = p.hw[2], *D = p.hw[3], *E = p.hw[4], *F = p.hw[5], *G = p.hw[6], *H = p.hw[7],
-                *I = p.hw[8], *Z = p.hw[9], *sun = p.hw[10];
     float r3[3];
-#if MIL_STRICT
-    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
-    float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
-    float vx = mrow(p.inv_proj, 0, px, py, d, 1.0f), vy = mrow(p.inv_proj, 1, px, py, d, 1.0f);
-    float vz = mrow(p.inv_proj, 2, px, py, d, 1.0f), vw = mrow(p.inv_proj, 3, px, py, d, 1.0f);
-    vx = vx / vw; vy = vy / vw; vz = vz / vw; vw = vw / vw;
-    f3 P = { mrow(p.inv_view, 0, vx, vy, vz, vw), mrow(p.inv_view, 1, vx, vy, vz, vw), mrow(p.inv_view, 2, vx, vy, vz, vw) };
-    f3 vd = normalize3(f3{ P.x - p.cam[0], P.y - p.cam[1], P.z - p.cam[2] });                    // :56-58
-    const float cg = fmaxf(0.001f, dot3(f3{ sun[0], sun[1], sun[2] }, vd));                      // :46
-    const float ct = fmaxf(0.001f, (vd.x * 0.0f + vd.y * 1.0f) + vd.z * 0.0f);                   // :47
-    const float gamma = (float)acos((double)cg);                                                 // :49 (exp / pow / acos in double, as the oracle)
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float chi = (1.0f + cg * cg) / (float)pow((double)((1.0f + H[c] * H[c]) - (2.0f * H[c]) * cg), 1.5);   // :39
-        const float left = 1.0f + A[c] * (float)exp((double)(B[c] / (ct + 0.01f)));              // :41
-        const float right = (((C[c] + D[c] * (float)exp((double)(E[c] * gamma))) + (F[c] * cg) * cg) + G[c] * chi) + I[c] * sqrtf(ct);
-        r3[c] = ((left * right) * Z[c]) * 0.05f;                                                 // :51, :58
-    }
-#else
-    const float xf = (float)x, yf = (float)(y + p.y_offset);
-    const float *m = p.pos_m;
-    // direction only: the w divide of PositionFromDepth is a positive scale the normalisation removes
-    f3 v = { __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, __builtin_fmaf(m[2], d, m[3]))),
-             __builtin_fmaf(m[4], xf, __builtin_fmaf(m[5], yf, __builtin_fmaf(m[6], d, m[7]))),
-             __builtin_fmaf(m[8], xf, __builtin_fmaf(m[9], yf, __builtin_fmaf(m[10], d, m[11]))) };
-    const float vw = __builtin_fmaf(m[12], xf, __builtin_fmaf(m[13], yf, __builtin_fmaf(m[14], d, m[15])));
-    const float rn = rsq_(dot3(v, v)) * (vw < 0.0f ? -1.0f : 1.0f);
-    const f3 vd = { v.x * rn, v.y * rn, v.z * rn };
-    const float cg = fmaxf(0.001f, dot3(f3{ sun[0], sun[1], sun[2] }, vd));
-    const float ct = fmaxf(0.001f, vd.y);
-    const float gamma = acosf(cg);
-    const float cg2 = cg * cg, sct = sqrt_(ct), ict = rcp_(ct + 0.01f);
-    const float LOG2E = 1.4426950408889634f;
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const float t = __builtin_fmaf(-2.0f * H[c], cg, __builtin_fmaf(H[c], H[c], 1.0f));       // 1 + H^2 - 2 H cos(gamma)
-        const float chi = (1.0f + cg2) * rsq_(t) * rcp_(t);                                       // t^-1.5
-        const float left = __builtin_fmaf(A[c], __builtin_amdgcn_exp2f(B[c] * ict * LOG2E), 1.0f);
-        const float right = __builtin_fmaf(I[c], sct, __builtin_fmaf(G[c], chi, __builtin_fmaf(F[c], cg2,
-                            __builtin_fmaf(D[c], __builtin_amdgcn_exp2f(E[c] * gamma * LOG2E), C[c]))));
-        r3[c] = left * right * (Z[c] * 0.05f);
-    }
-#endif
+    sky_radiance(p, x, y, d, r3);
     if (sky) __builtin_nontemporal_store(v4f{ r3[0], r3[1], r3[2], 1.0f }, (v4f *)p.hdr + (size_t)y * p.hdr_pitch + x);
 }
 
@@ -1283,38 +1391,30 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 {
     const uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
     if (x >= p.width || y >= p.height) return;
-    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const h4 a = __builtin_nontemporal_load((const h4 *)p.accum + (size_t)y * p.accum_pitch + x);
     const float r = (float)__builtin_nontemporal_load((const _Float16 *)p.reveal + (size_t)y * p.reveal_pitch + x);
-    const float ar = (float)a.x, ag = (float)a.y, ab = (float)a.z, aa = (float)a.w;
 #if !MIL_STRICT
-    if (__builtin_amdgcn_ballot_w64(!(r == 1.0f && ar == 0.0f && ag == 0.0f && ab == 0.0f)) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(!resolve_untouched(a, r)) == 0) return;
 #endif
     v4f *dst = (v4f *)p.hdr + (size_t)y * p.hdr_pitch + x;
-    const v4f h = *dst;
-    const float den = fminf(5e4f, fmaxf(1e-4f, aa)), om = 1.0f - r;
-#if MIL_STRICT
-    const v4f o = { (ar / den) * om + h.x * r, (ag / den) * om + h.y * r, (ab / den) * om + h.z * r, r * om + h.w * r };
-#else
-    const float k = rcp_(den) * om;
-    const v4f o = { __builtin_fmaf(ar, k, h.x * r), __builtin_fmaf(ag, k, h.y * r), __builtin_fmaf(ab, k, h.z * r), __builtin_fmaf(r, om, h.w * r) };
-#endif
+    const v4f o = resolve_blend(a, r, *dst);
     __builtin_nontemporal_store(o, dst);
 }
 
 // ---------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------
-void launch_stream(int fmt, const ShadeParams &p, hipStream_t s)
+void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {
-    const bool four = p.rows_per_block == 4;
+    const bool four = p.rows_per_block == 4 && !frame;
     dim3 block(64, 4), grid((p.width + 63) / 64, four ? (p.height + 15) / 16 : (p.height + 3) / 4);
     const bool ext = p.has_shadow || p.n_point || p.has_ambient;
-#define MIL_LAUNCH_STREAM(F)                                                              \
-    if (four) { if (ext) hipLaunchKernelGGL((k_stream<F, 4, true>), grid, block, 0, s, p);  \
-                else hipLaunchKernelGGL((k_stream<F, 4, false>), grid, block, 0, s, p); }   \
-    else { if (ext) hipLaunchKernelGGL((k_stream<F, 1, true>), grid, block, 0, s, p);       \
-           else hipLaunchKernelGGL((k_stream<F, 1, false>), grid, block, 0, s, p); }
+#define MIL_LAUNCH_STREAM(F)                                                                     \
+    if (frame) hipLaunchKernelGGL((k_stream<F, 1, true, true>), grid, block, 0, s, p);             \
+    else if (four) { if (ext) hipLaunchKernelGGL((k_stream<F, 4, true, false>), grid, block, 0, s, p);  \
+                     else hipLaunchKernelGGL((k_stream<F, 4, false, false>), grid, block, 0, s, p); }   \
+    else { if (ext) hipLaunchKernelGGL((k_stream<F, 1, true, false>), grid, block, 0, s, p);       \
+           else hipLaunchKernelGGL((k_stream<F, 1, false, false>), grid, block, 0, s, p); }
     switch (fmt) {
     case FMT_HDR: MIL_LAUNCH_STREAM(FMT_HDR); break;
     case FMT_LDR: MIL_LAUNCH_STREAM(FMT_LDR); break;
@@ -1323,17 +1423,21 @@ void launch_stream(int fmt, const ShadeParams &p, hipStream_t s)
     }
 #undef MIL_LAUNCH_STREAM
 }
-void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s)
+void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {
     const uint32_t wpb = (p.tune & 2u) ? 1 : ((p.tune & 4u) ? 2 : 4);
     dim3 block(64 * wpb), grid(((p.tiles_x + wpb - 1) / wpb) * p.tiles_y);
-    const size_t lds = (size_t)wpb * tiled_lds(p.n_point, p.has_shadow && p.shadow_lds && p.n_dir).per_wave;
+    const size_t lds = (size_t)wpb * tiled_lds(p.n_point, p.has_shadow && p.shadow_lds && p.n_dir, frame && p.accum && p.resolve_dma).per_wave;
+#define MIL_LAUNCH_TILED(F)                                                             \
+    if (frame) hipLaunchKernelGGL((k_tiled<F, true>), grid, block, lds, s, p);            \
+    else hipLaunchKernelGGL((k_tiled<F, false>), grid, block, lds, s, p);
     switch (fmt) {
-    case FMT_HDR: hipLaunchKernelGGL(k_tiled<FMT_HDR>, grid, block, lds, s, p); break;
-    case FMT_LDR: hipLaunchKernelGGL(k_tiled<FMT_LDR>, grid, block, lds, s, p); break;
-    case FMT_SRGB8: hipLaunchKernelGGL(k_tiled<FMT_SRGB8>, grid, block, lds, s, p); break;
-    default: hipLaunchKernelGGL(k_tiled<FMT_SRGB8_VIA_LDR>, grid, block, lds, s, p); break;
+    case FMT_HDR: MIL_LAUNCH_TILED(FMT_HDR); break;
+    case FMT_LDR: MIL_LAUNCH_TILED(FMT_LDR); break;
+    case FMT_SRGB8: MIL_LAUNCH_TILED(FMT_SRGB8); break;
+    default: MIL_LAUNCH_TILED(FMT_SRGB8_VIA_LDR); break;
     }
+#undef MIL_LAUNCH_TILED
 }
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
 {

@@ -46,6 +46,12 @@ struct ShadeParams {
     uint32_t *tile_counts;      // optional per-tile list length (diagnostics)
     uint32_t *tile_stamps;      // optional 4 x u32 per tile: start, end (100 MHz ticks), list length, HW_ID (diagnostics)
     const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
+    // whole-frame launch (mil_shade_frame): the sky and transparency-resolve subpasses folded into the store
+    uint32_t has_sky;
+    uint32_t accum_pitch, reveal_pitch;
+    uint32_t resolve_dma;             // K2 may fetch accum / reveal tiles by dword LDS-DMA (even width and pitch, 4-byte aligned base)
+    const uint16_t *accum, *reveal;   // RGBA16F / R16F; accum NULL = no resolve
+    float hw[11][4];                  // HosekWilkieParams: A B C D E F G H I Z sun_direction
 };
 
 struct TonemapParams {
@@ -79,8 +85,8 @@ struct ResolveParams {        // transparency resolve: accum RGBA16F + reveal R1
 
 // implemented once per numeric mode
 namespace fast {
-void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
-void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
+void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
+void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
 void launch_fxaa(const FxaaParams &p, hipStream_t s);
@@ -88,8 +94,8 @@ void launch_sky(const SkyParams &p, hipStream_t s);
 void launch_resolve(const ResolveParams &p, hipStream_t s);
 }
 namespace strict {
-void launch_stream(int fmt, const ShadeParams &p, hipStream_t s);
-void launch_tiled(int fmt, const ShadeParams &p, hipStream_t s);
+void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
+void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 void launch_fxaa(const FxaaParams &p, hipStream_t s);
 void launch_sky(const SkyParams &p, hipStream_t s);

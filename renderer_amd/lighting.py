@@ -24,7 +24,7 @@ TILE = 16
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
-           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve']
+           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame']
 
 
 class MilError(RuntimeError):
@@ -46,6 +46,11 @@ class Shadow(ctypes.Structure):            # mil_shadow
 class Extras(ctypes.Structure):            # mil_extras
     _fields_ = [('point_lights', ctypes.c_void_p), ('n_point', ctypes.c_uint32),
                 ('ambient', ctypes.c_float * 3), ('shadow', ctypes.POINTER(Shadow))]
+
+
+class FramePasses(ctypes.Structure):      # mil_frame_passes
+    _fields_ = [('sky', ctypes.c_void_p), ('accum', ctypes.c_void_p), ('reveal', ctypes.c_void_p),
+                ('accum_pitch_px', ctypes.c_uint32), ('reveal_pitch_px', ctypes.c_uint32)]
 
 
 _lib = None
@@ -77,6 +82,8 @@ def load_library(path=LIB_PATH):
         lib.mil_tonemap.argtypes = [vp, vp, u32, u32, u32, vp, u32, ctypes.c_int, u32, vp]
         lib.mil_light_ex.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras), vp, u32,
                                      ctypes.c_int, u32, vp]
+        lib.mil_shade_frame.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras),
+                                        ctypes.POINTER(FramePasses), vp, u32, ctypes.c_int, u32, vp]
         lib.mil_fxaa.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, u32, u32, vp]
         lib.mil_sky_hosek.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, u32, vp]
         lib.mil_transparency_resolve.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp, u32, u32, vp]
@@ -197,6 +204,26 @@ class LightingPass:
     def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,
                  flags=0, out=None, stream=None):
         """Lighting with the build-defined extensions, optionally fused with the tonemap."""
+        return self._shade(gb, frame, lights, point_lights, ambient, shadow, None, fmt, flags, out, stream)
+
+    def shade_frame(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, sky=None, accum=None,
+                    reveal=None, fmt=OUT_LDR, flags=0, out=None, stream=None):
+        """Lighting -> sky -> transparency resolve -> tonemap (render/mod.rs:201-309) as ONE launch.
+        sky: 44 floats HosekWilkieParams or None; accum (h, w, 4) / reveal (h, w) float16 or None."""
+        t = self.torch
+        fp = FramePasses()
+        keep = []
+        if sky is not None:
+            prm = np.ascontiguousarray(sky, np.float32).reshape(44)
+            keep.append(prm)
+            fp.sky = prm.ctypes.data
+        if accum is not None:
+            assert accum.dtype == t.float16 and reveal.dtype == t.float16
+            fp.accum, fp.reveal = accum.data_ptr(), reveal.data_ptr()
+            fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
+        return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream)
+
+    def _shade(self, gb, frame, lights, point_lights, ambient, shadow, passes, fmt, flags, out, stream):
         t = self.torch
         h, w = gb['depth'].shape
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros((0, 8)), np.float32).reshape(-1, 8)
@@ -222,8 +249,13 @@ class LightingPass:
                    else t.empty((h, w), dtype=t.int32, device=self.device))
         pitch = out.stride(0) // 4 if fmt == OUT_HDR else out.stride(0)
         g = self._gb(gb)
-        self._check(self.lib.mil_light_ex(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
-                                          ctypes.byref(ex), out.data_ptr(), pitch, fmt, flags, self._stream(stream)))
+        if passes is None:
+            self._check(self.lib.mil_light_ex(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
+                                              ctypes.byref(ex), out.data_ptr(), pitch, fmt, flags, self._stream(stream)))
+        else:
+            self._check(self.lib.mil_shade_frame(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
+                                                 ctypes.byref(ex), ctypes.byref(passes), out.data_ptr(), pitch, fmt, flags,
+                                                 self._stream(stream)))
         return out
 
     def count_pairs(self, gb, frame, point_lights, stream=None):

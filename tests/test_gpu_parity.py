@@ -441,6 +441,69 @@ def test_transparency_resolve(lp, coracle):
         assert np.array_equal(fast[rev == 1], hdr0[rev == 1])               # nothing transparent there: hdr untouched
 
 
+def test_shade_frame_equals_subpass_chain(lp):
+    """mil_shade_frame (one launch) == mil_light_ex(HDR) -> mil_sky_hosek -> mil_transparency_resolve -> mil_tonemap,
+    bit for bit in both numeric modes, on the streaming (no point lights) and the tiled kernel, whole frame and strip."""
+    from test_oracle_kat import sky_test_params, transparency_test_inputs
+    prm = sky_test_params()
+    for scene, (w, h), n_point, shadow in [('sweep', (320, 180), 40, 256), ('sweep', (67, 35), 0, 0), ('noise', (96, 64), 12, 0),
+                                           ('sweep', (200, 120), 0, 128)]:
+        gb, frame, dl, pl, sh = make_scene(scene, w, h, n_point=n_point, shadow=shadow)
+        gb['depth'][h // 3, : w // 2] = 1.0                                  # texels at the clear depth whatever their occlusion
+        acc, rev = transparency_test_inputs(h, w, seed=w)
+        ta, tr = torch.from_numpy(acc).to(DEV), torch.from_numpy(rev).to(DEV)
+        for flags in (0, lighting.FLAG_STRICT):
+            st = bool(flags & lighting.FLAG_STRICT)
+            for use_sky, use_acc in [(True, True), (True, False), (False, True), (False, False)]:
+                hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=flags)
+                if use_sky: lp.sky_hosek(gb, frame, prm, hdr, strict=st)
+                if use_acc: lp.transparency_resolve(ta, tr, hdr, strict=st)
+                kw = dict(sky=prm if use_sky else None, accum=ta if use_acc else None, reveal=tr if use_acc else None, flags=flags)
+                one = lp.shade_frame(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_HDR, **kw)
+                assert torch.equal(one.view(torch.int32), hdr.view(torch.int32)), (scene, w, h, flags, use_sky, use_acc, 'hdr')
+                for fmt in (lighting.OUT_LDR, lighting.OUT_SRGB8, lighting.OUT_SRGB8_VIA_LDR):
+                    one = lp.shade_frame(gb, frame, dl, pl, AMB, sh, fmt=fmt, **kw)
+                    assert torch.equal(one, lp.tonemap(hdr, fmt, strict=st)), (scene, w, h, flags, use_sky, use_acc, fmt)
+            # a strip of the frame == those rows of the whole frame
+            y0, y1 = 16, 32
+            strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+            strip['y_offset'] = y0
+            full = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, flags=flags)
+            part = lp.shade_frame(strip, frame, dl, pl, AMB, sh, sky=prm, accum=ta[y0:y1], reveal=tr[y0:y1], flags=flags)
+            assert torch.equal(part, full[y0:y1])
+    # no passes at all == mil_light_ex; bad arguments
+    gb, frame, dl, pl, sh = make_scene('sweep', 128, 72, n_point=8)
+    assert torch.equal(lp.shade_frame(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_LDR), lp.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_LDR))
+    fp = lighting.FramePasses()
+    fp.accum = 1
+    import ctypes
+    out = torch.empty((72, 128), dtype=torch.int32, device=DEV)
+    g = lp._gb(gb)
+    push = lighting.ubo.push_constants(128, 72, 0)
+    fr = np.ascontiguousarray(frame, np.float32).reshape(68)
+    assert lp.lib.mil_shade_frame(lp.ctx, ctypes.byref(g), fr.ctypes.data, None, push.ctypes.data, None, ctypes.byref(fp),
+                                  out.data_ptr(), 128, 1, 0, None) == -1          # accum without reveal
+
+
+def test_shade_frame_4k_chain(lp):
+    """The whole 4K frame: one launch + FXAA == the five-call chain, and the ldr image against the oracle on a band."""
+    from test_oracle_kat import sky_test_params
+    w, h = 3840, 2160
+    prm = sky_test_params()
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=256, shadow=2048)
+    acc = torch.zeros((h, w, 4), dtype=torch.float16, device=DEV); rev = torch.ones((h, w), dtype=torch.float16, device=DEV)
+    acc[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = torch.tensor([0.5, 0.4, 0.3, 0.8], dtype=torch.float16, device=DEV)
+    rev[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = 0.4
+    hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    lp.sky_hosek(gb, frame, prm, hdr); lp.transparency_resolve(acc, rev, hdr)
+    ldr = lp.tonemap(hdr, lighting.OUT_LDR)
+    one = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=acc, reveal=rev, fmt=lighting.OUT_LDR)
+    assert torch.equal(one, ldr)
+    assert torch.equal(lp.fxaa(one), lp.fxaa(ldr))
+    sky = gb['depth'] >= 1
+    assert sky.float().mean() > 0.3 and torch.all(hdr[sky][:, :3].sum(-1) > 0)   # the sky half of Scene A is no longer black
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE.json sizes)
 def test_4k_properties(lp):
     w, h = 3840, 2160

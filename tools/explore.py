@@ -87,6 +87,21 @@ if not os.environ.get('K1ONLY') and not os.environ.get('HLONLY'):
     print(f'{"sky (49 % of the texels)":50s} {timeit(sk):9.1f} us')
     print(f'{"transparency resolve (1/6 of the frame covered)":50s} {timeit(rs):9.1f} us')
     print(f'{"whole frame: light+sky+resolve+tonemap+fxaa":50s} {timeit(chain):9.1f} us')
+    def one(sky=True, tr=True, fmt=1):
+        def f():
+            i = it[0] % 3; it[0] += 1
+            lp.shade_frame(gbs[i], frame, dl, pl, amb, sh, sky=prm if sky else None, accum=acc if tr else None, reveal=rev if tr else None,
+                           fmt=fmt, out=(ldrs[i] if fmt else hdrs[i]))
+        return f
+    def fused():
+        i = it[0] % 3; it[0] += 1
+        lp.shade_frame(gbs[i], frame, dl, pl, amb, sh, sky=prm, accum=acc, reveal=rev, fmt=1, out=ldrs[i]); lp.fxaa(ldrs[i], out=outs[i])
+    print(f'{"shade_frame light+sky+resolve -> ldr (1 launch)":50s} {timeit(one()):9.1f} us')
+    print(f'{"shade_frame light+sky -> ldr":50s} {timeit(one(tr=False)):9.1f} us')
+    print(f'{"shade_frame light+resolve -> ldr":50s} {timeit(one(sky=False)):9.1f} us')
+    print(f'{"shade_frame light -> ldr":50s} {timeit(one(False, False)):9.1f} us')
+    print(f'{"shade_frame light+sky+resolve -> hdr":50s} {timeit(one(fmt=0)):9.1f} us')
+    print(f'{"whole frame: shade_frame + fxaa (2 launches)":50s} {timeit(fused):9.1f} us')
 # memcpy reference: copy 16 B/px in, 16 B/px out
 if os.environ.get('K1ONLY') or os.environ.get('HLONLY'): sys.exit(0)
 a = torch.empty(W * H * 4, device=dev); b = torch.empty_like(a)
