@@ -119,6 +119,50 @@ def kernel_burst(torch, lighting, lp, inp, n, fused, flags, which='light'):
     return e0.elapsed_time(e1) / n
 
 
+def frame_chain(torch, lighting, synth, lp, inp, n):
+    dev = lp.device
+    w, h, n_sets = inp['w'], inp['h'], len(inp['sets'])
+    prm = synth.hosek_params_synthetic()
+    acc, rev = synth.transparency_layer(w, h, dev)
+    hdr = [torch.empty((h, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
+    ldr = [torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
+    out = [torch.empty((h, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
+    args = (inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'])
+
+    def chain(i):
+        s = i % n_sets
+        lp.light_ex(inp['sets'][s], *args, out=hdr[s])
+        lp.sky_hosek(inp['sets'][s], inp['frame'], prm, hdr[s])
+        lp.transparency_resolve(acc, rev, hdr[s])
+        lp.tonemap(hdr[s], lighting.OUT_LDR, out=ldr[s])
+        lp.fxaa(ldr[s], out=out[s])
+
+    def one(i):
+        s = i % n_sets
+        lp.shade_frame(inp['sets'][s], *args, sky=prm, accum=acc, reveal=rev, fmt=lighting.OUT_LDR, out=ldr[s])
+        lp.fxaa(ldr[s], out=out[s])
+
+    def shade_only(i):
+        s = i % n_sets
+        lp.shade_frame(inp['sets'][s], *args, sky=prm, accum=acc, reveal=rev, fmt=lighting.OUT_LDR, out=ldr[s])
+
+    def burst(fn):
+        for i in range(5):
+            fn(i)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    c, o, so = burst(chain), burst(one), burst(shade_only)
+    px = w * h
+    return dict(five_call_chain_ms=round(c, 4), shade_frame_plus_fxaa_ms=round(o, 4), shade_frame_ms=round(so, 4),
+                mpix_s=round(px / o / 1e3, 1), passes='2 dir + PCF + 256 point + ambient, sky on 49 % of the texels, resolve over 1/6')
+
+
 def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0, pipelined=True):
     """Returns seconds for `steps` steps [max over ranks]."""
     from renderer_amd import sharding
@@ -321,6 +365,9 @@ def main():
                                              hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                              algorithmic_bytes=b1)}
         del inp1
+        # side measurement: the reference's whole frame, G-buffer -> swapchain image (render/mod.rs:189-329: lighting, sky,
+        # transparency resolve, tonemap, FXAA), as the five-call chain and as mil_shade_frame + mil_fxaa (hdr never stored)
+        res['extra']['frame_4k_gbuffer_to_swapchain'] = frame_chain(torch, lighting, synth, lp, inp, max(args.steps, 20))
     if not args.no_cpu and world == 1:
         res['cpu_baseline'] = cpu_baseline(inp)
     print(json.dumps(res))

@@ -207,3 +207,24 @@ def to_numpy(gb):
                 rough_metal=gb['rough_metal'].cpu().numpy().view(np.uint32),
                 depth=gb['depth'].cpu().numpy(),
                 width=gb['width'], height=gb['height'], y_offset=gb['y_offset'])
+
+
+def hosek_params_synthetic():
+    """Synthetic HosekWilkieParams, (11, 4) float32 = the std140 block of render/hosek/mod.rs:222-256 (the model's
+    dataset evaluation is CPU-side and out of scope): magnitudes of a turbidity-3 configuration, distinct per channel."""
+    prm = np.zeros((11, 4), np.float32)
+    prm[:, :3] = [[-1.1, -1.15, -1.2], [-0.2, -0.25, -0.3], [5.0, 4.0, 2.5], [1.0, 1.2, 0.9], [-3.0, -3.5, -2.5], [0.4, 0.3, 0.5],
+                  [0.15, 0.2, 0.1], [0.7, 0.6, 0.65], [0.6, 0.7, 0.5], [12.0, 14.0, 18.0], [0.3, 0.8, 0.52]]
+    prm[10, :3] /= np.linalg.norm(prm[10, :3])
+    return prm
+
+
+def transparency_layer(w, h, device):
+    """accum (h, w, 4) / reveal (h, w) float16 of a weighted-blended OIT pass (render/mcguire13/mod.rs:22-23) with one
+    translucent rectangle over the middle sixth of the frame; the rest holds the clear values (0, 1)."""
+    import torch
+    acc = torch.zeros((h, w, 4), dtype=torch.float16, device=device)
+    rev = torch.ones((h, w), dtype=torch.float16, device=device)
+    acc[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = torch.tensor([0.5, 0.4, 0.3, 0.8], dtype=torch.float16, device=device)
+    rev[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = 0.4
+    return acc, rev

@@ -485,6 +485,34 @@ def test_shade_frame_equals_subpass_chain(lp):
                                   out.data_ptr(), 128, 1, 0, None) == -1          # accum without reveal
 
 
+def test_shade_frame_strict_vs_oracle_chain(lp, coracle):
+    """Strict whole-frame launch against the C oracle's subpass chain (shade -> sky -> resolve -> tonemap), and the fast
+    launch against the float64 chain."""
+    from test_oracle_kat import sky_test_params, transparency_test_inputs
+    prm = sky_test_params()
+    w, h = 160, 96
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=24, shadow=128)
+    acc, rev = transparency_test_inputs(h, w, seed=3)
+    ta, tr = torch.from_numpy(acc).to(DEV), torch.from_numpy(rev).to(DEV)
+    planes = planes_np(gb)
+    lit = coracle.shade(*planes, frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh))
+    ref = coracle.sky_hosek(planes[3], frame, prm, lit.copy())
+    ref = coracle.transparency_resolve(acc, rev, ref)
+    S = lighting.FLAG_STRICT
+    got = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=lighting.OUT_HDR, flags=S).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=3e-7, atol=0)                  # sky: exp / pow / acos to their last ulp
+    sky = planes[3] >= 1
+    assert_bits_equal(got[~sky], ref[~sky], 'frame strict, non-sky texels')
+    ldr = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=lighting.OUT_LDR, flags=S).cpu().numpy().view(np.uint32)
+    ref_ldr = coracle.tonemap(ref, 1)
+    assert (ldr != ref_ldr).mean() < 2e-3                                    # a last-ulp sky difference may flip a rounding
+    assert np.array_equal(ldr[~sky], ref_ldr[~sky])
+    r64 = mo.transparency_resolve(acc, rev, mo.sky_hosek(planes[3], frame, prm, lit.astype(np.float64)))
+    fast = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=lighting.OUT_HDR).cpu().numpy()
+    bad = np.abs(fast - r64) > 2e-3 + 1e-3 * np.abs(r64)
+    assert bad.mean() < 1e-3
+
+
 def test_shade_frame_4k_chain(lp):
     """The whole 4K frame: one launch + FXAA == the five-call chain, and the ldr image against the oracle on a band."""
     from test_oracle_kat import sky_test_params

@@ -297,14 +297,7 @@ def test_fxaa_golden_fixture(coracle):
 
 
 # ------------------------------------------------------------------ next rows f-4 (sky) and f-2 (transparency resolve)
-def sky_test_params():
-    """Synthetic HosekWilkieParams (the model's dataset evaluation is CPU-side and out of scope): magnitudes of
-    a turbidity-3 configuration, distinct per channel."""
-    prm = np.zeros((11, 4), np.float32)
-    prm[:, :3] = [[-1.1, -1.15, -1.2], [-0.2, -0.25, -0.3], [5.0, 4.0, 2.5], [1.0, 1.2, 0.9], [-3.0, -3.5, -2.5], [0.4, 0.3, 0.5],
-                  [0.15, 0.2, 0.1], [0.7, 0.6, 0.65], [0.6, 0.7, 0.5], [12.0, 14.0, 18.0], [0.3, 0.8, 0.52]]
-    prm[10, :3] /= np.linalg.norm(prm[10, :3])
-    return prm
+sky_test_params = synth.hosek_params_synthetic
 
 
 def test_kat9_sky_and_resolve_hand_derived(coracle):
