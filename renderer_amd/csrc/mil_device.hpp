@@ -717,6 +717,61 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
     }
 }
 
+#if !MIL_STRICT
+// K1, two pixels per lane: the lane shades (x, y) and (x, y + 4) together in packed FP32 (the template instantiation K2
+// uses: v_pk_fma_f32 / v_pk_mul_f32, one issue slot for both pixels).  The one-pixel kernel spends 72 % of its SIMD
+// cycles in the VALU pipe beside its HBM stream; halving the issue count leaves the stream as the only bound.  Block =
+// 64 x 4 lanes over 64 x 8 pixels: every wave still reads whole 256-byte row segments and writes whole 1 KiB HDR rows.
+// A wave whose 128 pixels all have occlusion 0 (cleared G-buffer, render/mod.rs:129-131) stores its exact zeros unshaded.
+template <int FMT, bool EXT, bool FRAME>
+__global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
+{
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, xc = min(x, p.width - 1), ylast = p.height - 1;
+    const uint32_t ya = blockIdx.y * 8 + threadIdx.y, yb = ya + 4;
+    const size_t ia = (size_t)min(ya, ylast) * p.pitch + xc, ib = (size_t)min(yb, ylast) * p.pitch + xc;
+    const v2u w2 = { __builtin_nontemporal_load(p.albedo + ia), __builtin_nontemporal_load(p.albedo + ib) };
+    const v2u u1 = { __builtin_nontemporal_load(p.normal + ia), __builtin_nontemporal_load(p.normal + ib) };
+    const v2u u3 = { __builtin_nontemporal_load(p.rm + ia), __builtin_nontemporal_load(p.rm + ib) };
+    const v2f depth = { __builtin_nontemporal_load(p.depth + ia), __builtin_nontemporal_load(p.depth + ib) };
+    if (x >= p.width || ya > ylast) return;
+    const bool inB = yb <= ylast;
+    const bool litA = (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
+    if (__builtin_amdgcn_ballot_w64(litA || litB) == 0) {
+        emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ 0.0f, 0.0f, 0.0f });
+        if (inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ 0.0f, 0.0f, 0.0f });
+        return;
+    }
+    Px2 q;
+    setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + p.y_offset), (float)(yb + p.y_offset) }, depth), u1, w2, u3);
+    V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+    const bool sh = EXT && p.has_shadow && p.n_dir > 0;
+    v2f shadow = { 1.0f, 1.0f };
+    if (sh) {
+        if (litA) shadow.x = pcf_direct(shadow_tap(f3{ q.P.x.x, q.P.y.x, q.P.z.x }, p), p);
+        if (litB) shadow.y = pcf_direct(shadow_tap(f3{ q.P.x.y, q.P.y.y, q.P.z.y }, p), p);
+    }
+    for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, sh && l == 0, r);   // fs_deferred_lighting.glsl:62-64
+    if (EXT) {
+        for (uint32_t l = 0; l < p.n_point; l++) {
+            const v4f a = point_rec_a(p, l);
+            V3<v2f> Lv;
+            const v2f d2 = point_d2_2(q, a, Lv);
+            const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
+            if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;
+            point_eval2(q, point_rec_b(p, l), Lv, d2, on0, on1, r);
+        }
+        if (p.has_ambient) {
+            const v2f ka = q.occ * (1.0f / 255.0f);
+            r.x = fma_((v2f)(p.ambient[0]), tof(w2 & 0xFFu) * ka, r.x);
+            r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
+            r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
+        }
+    }
+    emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ r.x.x, r.y.x, r.z.x });
+    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ r.x.y, r.y.y, r.z.y });
+}
+#endif
+
 // ---------------------------------------------------------------------------------
 // K2: tiled kernel.  ONE WAVE PER 16x16 SCREEN TILE, no workgroup barrier anywhere: a
 // 256-thread workgroup is four independent waves on four horizontally adjacent tiles (so
@@ -1406,9 +1461,26 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 // ---------------------------------------------------------------------------------
 void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {
+    const bool ext = p.has_shadow || p.n_point || p.has_ambient;
+#if !MIL_STRICT
+    if (!(p.tune & 256u) && p.rows_per_block != 4) {      // two pixels per lane, packed (MIL_TUNE bit 256: the one-pixel kernel)
+        dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 7) / 8);
+#define MIL_LAUNCH_STREAM2(F)                                                                  \
+        if (frame) hipLaunchKernelGGL((k_stream2<F, true, true>), grid, block, 0, s, p);         \
+        else if (ext) hipLaunchKernelGGL((k_stream2<F, true, false>), grid, block, 0, s, p);     \
+        else hipLaunchKernelGGL((k_stream2<F, false, false>), grid, block, 0, s, p);
+        switch (fmt) {
+        case FMT_HDR: MIL_LAUNCH_STREAM2(FMT_HDR); break;
+        case FMT_LDR: MIL_LAUNCH_STREAM2(FMT_LDR); break;
+        case FMT_SRGB8: MIL_LAUNCH_STREAM2(FMT_SRGB8); break;
+        default: MIL_LAUNCH_STREAM2(FMT_SRGB8_VIA_LDR); break;
+        }
+#undef MIL_LAUNCH_STREAM2
+        return;
+    }
+#endif
     const bool four = p.rows_per_block == 4 && !frame;
     dim3 block(64, 4), grid((p.width + 63) / 64, four ? (p.height + 15) / 16 : (p.height + 3) / 4);
-    const bool ext = p.has_shadow || p.n_point || p.has_ambient;
 #define MIL_LAUNCH_STREAM(F)                                                                     \
     if (frame) hipLaunchKernelGGL((k_stream<F, 1, true, true>), grid, block, 0, s, p);             \
     else if (four) { if (ext) hipLaunchKernelGGL((k_stream<F, 4, true, false>), grid, block, 0, s, p);  \
