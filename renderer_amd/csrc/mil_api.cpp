@@ -46,6 +46,7 @@ struct mil_ctx {
     uint32_t *tile_counts = nullptr;
     uint32_t *tile_stamps = nullptr;
     uint32_t tune = 0;
+    uint32_t tonemap_rows = 0;   // K4 rows per lane (env MIL_TONEMAP_ROWS; tuning only)
     uint32_t k1_rows = 1;   // K1 pixels per lane: 1 or 4 (env MIL_K1_ROWS overrides; tuning only)
     int last_hip = 0;
 };
@@ -295,6 +296,7 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
     c->device = device;
     c->max_point = max_point_lights;
     if (const char *e = getenv("MIL_TUNE")) c->tune = (uint32_t)atoi(e);
+    if (const char *e = getenv("MIL_TONEMAP_ROWS")) c->tonemap_rows = (uint32_t)atoi(e);
     if (const char *e = getenv("MIL_K1_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->k1_rows = (uint32_t)v; }
     c->slot_bytes = 2 * (size_t)MIL_MAX_DIR_LIGHTS * 32 + (size_t)max_point_lights * (32 + 32 + 16);
     int rc = set_device(c);
@@ -472,6 +474,7 @@ int mil_tonemap(mil_ctx *c, const float *hdr, uint32_t hdr_pitch_px, uint32_t wi
     p.hdr = (const float4 *)hdr; p.out = out; p.width = width; p.height = height;
     p.hdr_pitch = hdr_pitch_px; p.out_pitch = out_pitch_px;
     p.lut11 = c->lut; p.lut10 = c->lut + LUT11_N;
+    p.rows = c->tonemap_rows;
     if (flags & MIL_FLAG_STRICT) mil::strict::launch_tonemap((int)fmt, p, (hipStream_t)stream);
     else mil::fast::launch_tonemap((int)fmt, p, (hipStream_t)stream);
     return finish(c, nullptr, (hipStream_t)stream);

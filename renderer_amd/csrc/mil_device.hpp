@@ -1220,13 +1220,19 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 // ---------------------------------------------------------------------------------
 // K4: tonemap + pack (fs_tonemap.glsl:23-27).  Block = 64 x 4 pixels.
 // ---------------------------------------------------------------------------------
-template <int FMT>
+template <int FMT, int ROWS>
 __global__ __launch_bounds__(256) void k_tonemap(const TonemapParams p)
 {
-    uint32_t x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= p.width || y >= p.height) return;
-    v4f h = __builtin_nontemporal_load((const v4f *)p.hdr + (size_t)y * p.hdr_pitch + x);
-    __builtin_nontemporal_store(encode_ldr<FMT>(h.x, h.y, h.z, p.lut11, p.lut10), p.out + (size_t)y * p.out_pitch + x);
+    // ROWS rows per lane (y, y + 4, ...): all loads are issued before the first encode, so a wave keeps ROWS KiB in flight
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x, y0 = blockIdx.y * (4 * ROWS) + threadIdx.y;
+    if (x >= p.width || y0 >= p.height) return;
+    v4f h[ROWS];
+#pragma unroll
+    for (int j = 0; j < ROWS; j++) h[j] = __builtin_nontemporal_load((const v4f *)p.hdr + (size_t)min(y0 + 4 * j, p.height - 1) * p.hdr_pitch + x);
+#pragma unroll
+    for (int j = 0; j < ROWS; j++)
+        if (y0 + 4 * j < p.height)
+            __builtin_nontemporal_store(encode_ldr<FMT>(h[j].x, h[j].y, h[j].z, p.lut11, p.lut10), p.out + (size_t)(y0 + 4 * j) * p.out_pitch + x);
 }
 
 #if !MIL_STRICT
@@ -1513,12 +1519,18 @@ void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 }
 void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
 {
-    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
+    const uint32_t rows = p.rows == 1 || p.rows == 4 ? p.rows : 2;
+    dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 4 * rows - 1) / (4 * rows));
+#define MIL_LAUNCH_TONEMAP(F)                                                               \
+    if (rows == 1) hipLaunchKernelGGL((k_tonemap<F, 1>), grid, block, 0, s, p);               \
+    else if (rows == 2) hipLaunchKernelGGL((k_tonemap<F, 2>), grid, block, 0, s, p);          \
+    else hipLaunchKernelGGL((k_tonemap<F, 4>), grid, block, 0, s, p);
     switch (fmt) {
-    case FMT_LDR: hipLaunchKernelGGL(k_tonemap<FMT_LDR>, grid, block, 0, s, p); break;
-    case FMT_SRGB8: hipLaunchKernelGGL(k_tonemap<FMT_SRGB8>, grid, block, 0, s, p); break;
-    default: hipLaunchKernelGGL(k_tonemap<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p); break;
+    case FMT_LDR: MIL_LAUNCH_TONEMAP(FMT_LDR); break;
+    case FMT_SRGB8: MIL_LAUNCH_TONEMAP(FMT_SRGB8); break;
+    default: MIL_LAUNCH_TONEMAP(FMT_SRGB8_VIA_LDR); break;
     }
+#undef MIL_LAUNCH_TONEMAP
 }
 void launch_fxaa(const FxaaParams &p, hipStream_t s)
 {

@@ -59,6 +59,7 @@ struct TonemapParams {
     uint32_t *out;
     uint32_t width, height, hdr_pitch, out_pitch;
     const uint8_t *lut11, *lut10;
+    uint32_t rows;              // rows per lane: 1, 2 or 4 (tuning; 0 = default)
 };
 
 struct FxaaParams {
