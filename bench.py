@@ -9,9 +9,13 @@ A step = one pass of the hot path over one 3840x2160 synthetic G-buffer (Scene A
 shadow, 256 point lights culled per 16x16 tile into LDS lists, ambient) writing the
 RGBA32F hdr attachment, then the fused tonemap/gamma kernel (ACES + sRGB8).  Inputs are
 resident in HBM before the timed region; three buffer sets (> 256 MiB) rotate so the
-Infinity Cache cannot hold a frame.  N > 1: frame-parallel (each rank shades its own frame
-of an orbiting camera) with an overlapped grouped-P2P gather of the packed frames to GPU 0;
-per-GPU work is fixed, so scaling is "weak".  Rank 0 prints ONE JSON line.
+Infinity Cache cannot hold a frame.  N > 1: frame-parallel (each rank shades its own frames
+of an orbiting camera; the frames are independent units and no data-path collective joins
+them); per-GPU work is fixed, so scaling is "weak".  The same loop is then timed once more
+with every packed frame gathered to GPU 0 by overlapped grouped P2P (north_star's
+presentation step; bound by one xGMI link per sender, 33 MB per frame) and reported beside
+`value` as config.gather_to_gpu0.  --mode strips always gathers (one frame is assembled).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -163,7 +167,7 @@ def frame_chain(torch, lighting, synth, lp, inp, n):
                 mpix_s=round(px / o / 1e3, 1), passes='2 dir + PCF + 256 point + ambient, sky on 49 % of the texels, resolve over 1/6')
 
 
-def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0, pipelined=True):
+def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0, pipelined=True, gather=True):
     """Returns seconds for `steps` steps [max over ranks]."""
     from renderer_amd import sharding
     dev = lp.device
@@ -208,7 +212,7 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
             lp.tonemap(hdr[s], lighting.OUT_SRGB8, out=out[s], stream=post)
             tone_done[s].record(post)
             used[s] = True
-        if world > 1:
+        if world > 1 and gather:
             with torch.cuda.stream(post):
                 if strips:
                     pending[s] = sharding.gather_strips(out[s], bounds, slots[s], dst=0, async_op=True)
@@ -312,7 +316,11 @@ def main():
     pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if (inp['pl'] is not None and inp.get('lh', 1)) else 0
 
     dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
-                      pipelined=(args.pipelined and world == 1))
+                      pipelined=(args.pipelined and world == 1), gather=strips)
+    dt_gather = None
+    if world > 1 and not strips:       # the same frames, each gathered to GPU 0 (xGMI-bound)
+        dt_gather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
+                                 pipelined=False, gather=True)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -350,11 +358,15 @@ def main():
                                     f'(light 0 PCF {inp["shadow_size"]}^2) + {inp["n_point"]} point lights'
                                     + (' + ambient' if inp['amb'] else ''),
                            kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
-                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned) + P2P gather to GPU 0' if strips else f'frame-parallel x{world} + P2P gather to GPU 0')),
+                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned) + P2P gather to GPU 0' if strips else f'frame-parallel x{world}, frames stay on their GPUs')),
                            tonemap_ms=round(tone_burst_ms, 4),
                            streams=('1 (serial)' if (not args.pipelined or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),
                roofline=primary, roofline_other=other)
+    if dt_gather is not None:
+        res['config']['gather_to_gpu0'] = dict(value=round(world * args.steps * px / dt_gather / 1e6, 1), unit='Mpix/s',
+                                               ms_per_step=round(dt_gather / args.steps * 1e3, 4),
+                                               note='same loop with every packed sRGB8 frame (33.2 MB) sent to GPU 0 by grouped P2P over xGMI')
 
     if not args.no_extra and world == 1 and args.workload == 'headline':
         # side measurement: the HBM-bound 4K / 1-light lighting pass (BASELINE.md target >= 70 % of HBM roofline)
