@@ -297,10 +297,18 @@ def main():
                      '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
         args.gpus = world
     dist = None
+    # rehearsal on a one-GPU box only: MIL_BENCH_REHEARSE=1 puts every rank on device 0 and joins them over gloo
+    # (RCCL refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearse = os.environ.get('MIL_BENCH_REHEARSE') == '1'
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = f'cuda:{local_rank}'
 
     lp = lighting.LightingPass(local_rank, max_point_lights=4096)
@@ -337,7 +345,7 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     kname = 'k_tiled' if (inp['n_point'] or (inp['shadow_size'] and args.flags & 4)) else 'k_stream'
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and not strips:      # the PMC passes were taken on whole-frame launches
         t = json.load(open(tpath)).get(f'{args.workload}{"_fused" if args.fused else ""}:{kname}')
         if t:
             traffic = t['hbm_bytes_per_launch']
