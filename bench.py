@@ -62,11 +62,13 @@ def parse():
     return ap.parse_args()
 
 
-def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64, rows=None):
+def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64, rows=None, noise=False):
     from renderer_amd import sharding
     w, h, n_dir, n_point, shadow_size, ambient = WORKLOADS[wl]
     cam = synth.sweep_camera(w, h) if frame_idx is None else sharding.orbit_camera(frame_idx, n_frames, w, h)
     gb0 = synth.scene_sweep(w, h, cam, device=device, rows=rows)       # rows: this rank's strip (global rows, y_offset set)
+    if noise:        # Scene B: every plane i.i.d. random, every texel lit (nothing for an early-out to skip)
+        gb0 = synth.scene_noise(w, h, 0x5EED0000, device=device)
     sets = [gb0] + [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in gb0.items()} for _ in range(n_sets - 1)]
     dl = ubo.default_directional_lights()[:n_dir]
     pl = synth.point_light_field(n_point, 0x5EED0003) if n_point else None
@@ -384,6 +386,13 @@ def main():
         res['extra'] = {'k1_4k_1light': dict(kernel='k_stream -> hdr RGBA32F', ms=round(l1, 4), mpix_s=round(px / l1 / 1e3, 1),
                                              hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                              algorithmic_bytes=b1)}
+        del inp1
+        # the same pass on Scene B (noise, every texel lit): no wave can skip anything, so this is the pure streaming rate
+        inp1 = build_inputs(torch, synth, ubo, 'k1_1light', dev, args.sets, noise=True)
+        l1 = kernel_burst(torch, lighting, lp, inp1, max(args.steps, 20), False, 0)
+        res['extra']['k1_4k_1light_all_lit'] = dict(kernel='k_stream -> hdr RGBA32F, Scene B', ms=round(l1, 4), mpix_s=round(px / l1 / 1e3, 1),
+                                                    hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
+                                                    note='tools/probe/stream_probe.hip: the same four-plane access pattern with no arithmetic takes 43.6 us (6.09 TB/s), a float4 copy 41.6 us')
         del inp1
         # side measurement: the reference's whole frame, G-buffer -> swapchain image (render/mod.rs:189-329: lighting, sky,
         # transparency resolve, tonemap, FXAA), as the five-call chain and as mil_shade_frame + mil_fxaa (hdr never stored)
