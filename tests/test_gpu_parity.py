@@ -485,6 +485,23 @@ def test_shade_frame_equals_subpass_chain(lp):
                                   out.data_ptr(), 128, 1, 0, None) == -1          # accum without reveal
 
 
+def test_shade_frame_largest_lds_carve(lp):
+    """More than one chunk of point lights (stash in LDS) + LDS-staged shadow rectangle + LDS-staged accum / revealage:
+    every per-wave LDS region in use at once (56 KiB per workgroup); still == the chain of separate calls."""
+    from test_oracle_kat import sky_test_params, transparency_test_inputs
+    prm = sky_test_params()
+    w, h = 128, 80
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=1100, shadow=128)
+    acc, rev = transparency_test_inputs(h, w, seed=11)
+    ta, tr = torch.from_numpy(acc).to(DEV), torch.from_numpy(rev).to(DEV)
+    for flags in (lighting.FLAG_SHADOW_LDS, lighting.FLAG_SHADOW_LDS | lighting.FLAG_STRICT):
+        st = bool(flags & lighting.FLAG_STRICT)
+        hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=flags)
+        lp.sky_hosek(gb, frame, prm, hdr, strict=st); lp.transparency_resolve(ta, tr, hdr, strict=st)
+        one = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=lighting.OUT_HDR, flags=flags)
+        assert torch.equal(one.view(torch.int32), hdr.view(torch.int32)), flags
+
+
 def test_shade_frame_strict_vs_oracle_chain(lp, coracle):
     """Strict whole-frame launch against the C oracle's subpass chain (shade -> sky -> resolve -> tonemap), and the fast
     launch against the float64 chain."""
