@@ -486,11 +486,13 @@ int mil_fxaa(mil_ctx *c, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t wi
     if (!c || !ldr || !out || width == 0 || height == 0) return MIL_ERR_BAD_ARG;
     if (ldr_pitch_px < width || out_pitch_px < width) return MIL_ERR_BAD_ARG;
     if (row_count == 0 || (uint64_t)row_begin + row_count > height) return MIL_ERR_BAD_ARG;
+    if ((uint64_t)ldr_pitch_px * height >= (1ull << 30) || height >= (1u << 24) || ldr_pitch_px >= (1u << 24)) return MIL_ERR_BAD_ARG;   // 32-bit texel offsets in the kernels
     int rc = set_device(c);
     if (rc) return rc;
     mil::FxaaParams p;
     p.ldr = ldr; p.out = out; p.width = width; p.height = height; p.ldr_pitch = ldr_pitch_px; p.out_pitch = out_pitch_px;
     p.row_begin = row_begin; p.row_count = row_count;
+    p.lut11 = c->lut; p.lut10 = c->lut + LUT11_N;
     if (flags & MIL_FLAG_STRICT) mil::strict::launch_fxaa(p, (hipStream_t)stream);
     else mil::fast::launch_fxaa(p, (hipStream_t)stream);
     return finish(c, nullptr, (hipStream_t)stream);

@@ -1369,16 +1369,30 @@ __global__ __launch_bounds__(256) void k_fxaa2(const FxaaParams p)
 {
     const int lane = (int)threadIdx.x;
     const int col = (int)(blockIdx.x * 62) + lane - 1;                 // may be -1 or >= width: clamp to edge
-    const uint32_t yy = (blockIdx.y * 4 + threadIdx.y) * 2;             // first of the lane's two rows, strip-local
+    // the wave's rows are wave-uniform: row clamps and row base addresses are scalar work, the lane adds its column
+    const uint32_t yy = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.y * 4 + threadIdx.y) * 2));   // first of the two rows, strip-local
     if (yy >= p.row_count) return;                                      // whole wave
     const int y = (int)(p.row_begin + yy);
     const int xc = min(max(col, 0), (int)p.width - 1), H1 = (int)p.height - 1;
     f3 c[4];
     float L[4];
+    uint32_t u[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) u[r] = (p.ldr + (size_t)min(max(y - 1 + r, 0), H1) * p.ldr_pitch)[(uint32_t)xc];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        c[r] = fxaa_decode(p.ldr[(size_t)min(max(y - 1 + r, 0), H1) * p.ldr_pitch + xc]);
+        c[r] = fxaa_decode(u[r]);
         L[r] = fxaa_luma(c[r]);
+    }
+    // A pixel whose edge direction is shorter than one pixel keeps its centre texel (below), which is an R11G11B10F
+    // code: its sRGB8 value comes from the two tables of every code <= 1.0 (exact, the tonemap's VIA_LDR tables)
+    // instead of three log/exp evaluations.  Per pixel, not per wave, so a strip equals the rows of the whole frame.
+    uint32_t wl[2];
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const uint32_t t = u[1 + e];
+        wl[e] = (uint32_t)p.lut10[min(t >> 22, 0x1E0u)] | ((uint32_t)p.lut11[min((t >> 11) & 0x7FFu, 0x3C0u)] << 8) |
+                ((uint32_t)p.lut11[min(t & 0x7FFu, 0x3C0u)] << 16) | 0xFF000000u;
     }
     float Lw[4], Le[4];                                                  // the same rows, one column to the west / east
 #pragma unroll
@@ -1399,10 +1413,15 @@ __global__ __launch_bounds__(256) void k_fxaa2(const FxaaParams p)
     if (__builtin_amdgcn_ballot_w64(live && (edge0 || edge1)) != 0) {
 #pragma unroll
         for (int e = 0; e < 2; e++) {
+            if (__builtin_amdgcn_ballot_w64(live && (e ? edge1 : edge0)) == 0) continue;   // this row of the wave has no edge
             const float ddx = e ? dx.y : dx.x, ddy = e ? dy.y : dy.x;
             const float fx = (float)col + 0.5f, fy = (float)(y + e) + 0.5f;
-            auto tap = [&](float k) {
-                return fxaa_texel(p, (int)floorf(__builtin_fmaf(ddx, k, fx)), (int)floorf(__builtin_fmaf(ddy, k, fy)));
+            auto tap = [&](float k) {          // pixel offsets fit 30 bits (checked on the host): one 24-bit mad + scalar base
+                const int ix = min(max((int)floorf(__builtin_fmaf(ddx, k, fx)), 0), (int)p.width - 1);
+                const int iy = min(max((int)floorf(__builtin_fmaf(ddy, k, fy)), 0), H1);
+                const uint32_t off = __umul24((uint32_t)iy, p.ldr_pitch) + (uint32_t)ix;
+                __builtin_assume(off < (1u << 30));
+                return fxaa_decode(p.ldr[off]);
             };
             const f3 t0 = tap(K1), t1 = tap(K2), t2 = tap(-0.5f), t3 = tap(0.5f);
             const f3 a = { 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
@@ -1410,14 +1429,15 @@ __global__ __launch_bounds__(256) void k_fxaa2(const FxaaParams p)
                            __builtin_fmaf(0.25f, t2.z + t3.z, a.z * 0.5f) };
             const float lB = fxaa_luma(b), mn = e ? lmin.y : lmin.x, mx = e ? lmax.y : lmax.x;
             o[e] = (lB < mn || lB > mx) ? a : b;
+            const uint32_t w = srgb8_direct(sat(o[e].z)) | (srgb8_direct(sat(o[e].y)) << 8) | (srgb8_direct(sat(o[e].x)) << 16) | 0xFF000000u;
+            if (e ? edge1 : edge0) wl[e] = w;
         }
     }
     if (!live) return;
 #pragma unroll
     for (int e = 0; e < 2; e++) {
         if (yy + e >= p.row_count) break;
-        __builtin_nontemporal_store(srgb8_direct(sat(o[e].z)) | (srgb8_direct(sat(o[e].y)) << 8) | (srgb8_direct(sat(o[e].x)) << 16) | 0xFF000000u,
-                                    p.out + (size_t)(yy + e) * p.out_pitch + col);
+        __builtin_nontemporal_store(wl[e], (p.out + (size_t)(yy + e) * p.out_pitch) + (uint32_t)col);
     }
 }
 #endif

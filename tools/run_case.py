@@ -14,6 +14,7 @@ frame = cam.frame_matrix_data(); dl = ubo.default_directional_lights(); pl = syn
 sh = synth.shadow_setup(dl[0, :3], 2048, device=dev); amb = (0.03,) * 3
 hdrs = [torch.empty((H, W, 4), device=dev) for _ in range(3)]
 outs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(3)]
+ldrs = [lp.tonemap(lp.light_ex(gbs[0], frame, dl, pl, amb, sh), 1) for _ in range(3)] if case == 'fxaa' else None
 torch.cuda.synchronize()
 for i in range(iters):
     k = i % 3
@@ -26,5 +27,6 @@ for i in range(iters):
     elif case == 'hl_nodir': lp.light_ex(gbs[k], frame, dl[:0], pl, amb, None, out=hdrs[k])
     elif case == 'points': lp.light_ex(gbs[k], frame, dl[:0], pl, None, None, out=hdrs[k])
     elif case == 'tonemap': lp.tonemap(hdrs[k], 2, out=outs[k])
+    elif case == 'fxaa': lp.fxaa(ldrs[k], out=outs[k])
     else: raise SystemExit('unknown case')
 torch.cuda.synchronize()
