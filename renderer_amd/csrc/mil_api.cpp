@@ -90,6 +90,7 @@ int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push)
     if (!gb || !push) return MIL_ERR_BAD_ARG;
     if (!gb->normal_l_model || !gb->albedo_occlusion || !gb->roughness_metallic || !gb->depth) return MIL_ERR_BAD_ARG;
     if (gb->width == 0 || gb->height == 0 || gb->pitch_px < gb->width) return MIL_ERR_BAD_ARG;
+    if ((uint64_t)gb->pitch_px * gb->height >= (1ull << 30)) return MIL_ERR_BAD_ARG;   // the kernels use 32-bit texel offsets (1 Gpx per plane)
     if (!(push->resolution[0] >= 1.0f) || !(push->resolution[1] >= 1.0f)) return MIL_ERR_BAD_ARG;
     if ((float)gb->width > push->resolution[0]) return MIL_ERR_BAD_ARG;
     if ((double)gb->y_offset + (double)gb->height > (double)push->resolution[1]) return MIL_ERR_BAD_ARG;

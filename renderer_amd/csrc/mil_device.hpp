@@ -728,7 +728,8 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
 {
     const uint32_t x = blockIdx.x * 64 + threadIdx.x, xc = min(x, p.width - 1), ylast = p.height - 1;
     const uint32_t ya = blockIdx.y * 8 + threadIdx.y, yb = ya + 4;
-    const size_t ia = (size_t)min(ya, ylast) * p.pitch + xc, ib = (size_t)min(yb, ylast) * p.pitch + xc;
+    const uint32_t ia = min(ya, ylast) * p.pitch + xc, ib = min(yb, ylast) * p.pitch + xc;   // < 2^30 (checked on the host)
+    __builtin_assume(ia < (1u << 30)); __builtin_assume(ib < (1u << 30));
     const v2u w2 = { __builtin_nontemporal_load(p.albedo + ia), __builtin_nontemporal_load(p.albedo + ib) };
     const v2u u1 = { __builtin_nontemporal_load(p.normal + ia), __builtin_nontemporal_load(p.normal + ib) };
     const v2u u3 = { __builtin_nontemporal_load(p.rm + ia), __builtin_nontemporal_load(p.rm + ib) };
@@ -909,9 +910,9 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
     const bool xin = x < p.width;
     {
-        size_t i[4];
+        uint32_t i[4];       // texel offsets fit 30 bits (checked on the host): scalar plane base + one 32-bit lane offset per row
 #pragma unroll
-        for (int j = 0; j < 4; j++) i[j] = (size_t)min(y0 + 4 * j, ylast) * p.pitch + xc;
+        for (int j = 0; j < 4; j++) { i[j] = min(y0 + 4 * j, ylast) * p.pitch + xc; __builtin_assume(i[j] < (1u << 30)); }
 #pragma unroll
         for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.albedo + i[j]), (lptr_t)(s_tex + (4 + j) * 64), 4, 0, 0);
         if (rdma) {
