@@ -57,6 +57,8 @@ def parse():
     ap.add_argument('--pipelined', action='store_true',
                     help='N = 1: tonemap of frame i on a second stream beside the lighting of frame i + 1 (+3 %%; off by default so '
                          'that per-kernel durations under rocprofv3 are those of kernels running alone)')
+    ap.add_argument('--balance', action='store_true',
+                    help='--mode strips: cut the strips by cost (wave lifetimes of one calibration frame, exchanged by one all_gather) instead of by rows')
     ap.add_argument('--fused', action='store_true', help='one kernel: lighting + tonemap -> sRGB8 (20 B/px)')
     ap.add_argument('--flags', type=int, default=0, help='extra MIL_FLAG_* bits (experiments)')
     return ap.parse_args()
@@ -176,7 +178,7 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
     n_sets = len(inp['sets'])
     w, h = inp['w'], inp['h']
     strips = inp.get('rows') is not None
-    bounds = sharding.strip_bounds(h, world) if strips else None
+    bounds = inp.get('bounds') or (sharding.strip_bounds(h, world) if strips else None)
     lh = (inp['rows'][1] - inp['rows'][0]) if strips else h            # rows this rank shades
     hdr = [None if fused else torch.empty((lh, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
     out = [torch.empty((lh, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
@@ -320,6 +322,23 @@ def main():
         y0, y1 = sharding.strip_bounds(WORKLOADS[args.workload][1], world)[rank]
         inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, rows=(y0, y1))
         inp['lh'] = y1 - y0
+        if args.balance and world > 1 and inp['pl'] is not None:
+            # calibration frame on the equal-row strips: per-tile-row wave lifetimes -> all ranks -> the same weighted cuts
+            hgt = WORKLOADS[args.workload][1]
+            cost_local = np.zeros(0)
+            if y1 > y0:
+                st = lp.tile_stamps(inp['sets'][0])
+                lp.light_ex(inp['sets'][0], inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'])
+                torch.cuda.synchronize()
+                lp.tile_stamps(inp['sets'][0], enable=False)
+                cost_local = sharding.band_costs_from_stamps(st)
+            cost = sharding.exchange_band_costs(cost_local, y0, -(-hgt // 16), device=(None if rehearse else dev))
+            bounds = sharding.strip_bounds_weighted(cost, world, hgt)
+            y0, y1 = bounds[rank]
+            del inp
+            inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, rows=(y0, y1))
+            inp['lh'] = y1 - y0
+            inp['bounds'] = bounds
     else:
         inp = build_inputs(torch, synth, ubo, args.workload, dev, args.sets, frame_idx=(rank if world > 1 else None))
     px = inp['w'] * inp['h']
@@ -368,7 +387,7 @@ def main():
                                     f'(light 0 PCF {inp["shadow_size"]}^2) + {inp["n_point"]} point lights'
                                     + (' + ambient' if inp['amb'] else ''),
                            kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
-                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned) + P2P gather to GPU 0' if strips else f'frame-parallel x{world}, frames stay on their GPUs')),
+                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned{", cost-weighted " + str([b - a for a, b in inp["bounds"]]) if inp.get("bounds") else ""}) + P2P gather to GPU 0' if strips else f'frame-parallel x{world}, frames stay on their GPUs')),
                            tonemap_ms=round(tone_burst_ms, 4),
                            streams=('1 (serial)' if (not args.pipelined or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),

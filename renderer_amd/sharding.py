@@ -33,6 +33,71 @@ def strip_bounds(height, n, align=TILE):
     return list(zip(cuts[:-1], cuts[1:]))
 
 
+def strip_bounds_weighted(band_cost, n, height, align=TILE):
+    """n contiguous strips with cuts on multiples of `align` rows, chosen so that the most expensive strip is as cheap
+    as possible (cost-weighted boundaries).  band_cost[i] = cost of rows [i*align, (i+1)*align) - e.g. the
+    previous frame's wave lifetimes per tile row (band_costs_from_stamps).  Exact for the bottleneck objective: binary
+    search on the bottleneck, greedy feasibility.  Every rank computes the same cuts from the same costs."""
+    c = np.asarray(band_cost, np.float64)
+    nb = int(math.ceil(height / align))
+    assert c.shape == (nb,) and n >= 1 and np.all(c >= 0)
+    c = c + 1e-9 * (c.sum() + 1.0) / nb            # no zero-cost bands: keeps the cuts spread when costs are all 0
+
+    def cuts_for(limit):
+        cuts, acc = [0], 0.0
+        for i, v in enumerate(c):
+            if acc + v > limit and acc > 0.0:
+                cuts.append(i)
+                acc = 0.0
+            acc += v
+        return cuts
+
+    lo, hi = float(c.max()), float(c.sum())
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if len(cuts_for(mid)) <= n:
+            hi = mid
+        else:
+            lo = mid
+    cuts = cuts_for(hi)
+    cuts += [nb] * (n + 1 - len(cuts))               # fewer strips than ranks: trailing ranks get an empty strip
+    rows = [min(height, k * align) for k in cuts]
+    return list(zip(rows[:-1], rows[1:]))
+
+
+def rescale_band_costs(band_cost, bounds, strip_times, align=TILE):
+    """Feedback step of the balancing: the bands of every strip are rescaled so that they sum to the time that strip
+    actually took (measured by its rank).  Iterating  cuts -> times -> rescale -> cuts  equalises the strip times even
+    though wave lifetimes are not additive across strips."""
+    c = np.asarray(band_cost, np.float64).copy()
+    for (y0, y1), t in zip(bounds, strip_times):
+        if y1 > y0:
+            b0, b1 = y0 // align, -(-y1 // align)
+            tot = c[b0:b1].sum()
+            c[b0:b1] = c[b0:b1] * (t / tot) if tot > 0 else t / (b1 - b0)
+    return c
+
+
+def band_costs_from_stamps(stamps):
+    """Per tile row: the sum of the wave lifetimes (end - start, 100 MHz ticks, wrap-safe) that a culled launch wrote
+    into the (tiles_y, tiles_x, 4) stamp buffer (LightingPass.tile_stamps)."""
+    s = stamps.detach().cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    return (((s[..., 1] - s[..., 0]) & 0xFFFFFFFF).sum(1)).astype(np.float64)
+
+
+def exchange_band_costs(local_cost, y0, n_bands, group=None, device=None):
+    """Every rank contributes the band costs of its own strip (which starts at row y0); all ranks get the whole frame's
+    vector.  One all_gather of n_bands floats per rank: the only collective of the balancing step."""
+    world = dist.get_world_size(group)
+    mine = torch.zeros(n_bands, dtype=torch.float64, device=device)
+    b0 = y0 // TILE
+    lc = torch.as_tensor(np.asarray(local_cost, np.float64), device=device)
+    mine[b0:b0 + lc.numel()] = lc
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.stack(parts).sum(0).cpu().numpy()
+
+
 def frame_assignment(n_frames, world, rank):
     """Blocked deal of frame indices: rank r gets a contiguous run."""
     per = int(math.ceil(n_frames / world))

@@ -27,6 +27,25 @@ def test_strip_bounds():
     assert sum(len(sharding.frame_assignment(10, 4, r)) for r in range(4)) == 10
 
 
+def test_strip_bounds_weighted():
+    rng = np.random.RandomState(7)
+    for h, n in [(2160, 8), (4320, 8), (2160, 3), (720, 8), (90, 4), (16, 4)]:
+        nb = -(-h // 16)
+        for cost in (np.ones(nb), rng.rand(nb) ** 4, np.r_[np.zeros(nb // 2), np.ones(nb - nb // 2)], np.zeros(nb)):
+            b = sharding.strip_bounds_weighted(cost, n, h)
+            assert len(b) == n and b[0][0] == 0 and b[-1][1] == h
+            assert all(y0 % 16 == 0 for y0, y1 in b if y1 > y0) and all(a[1] == c[0] for a, c in zip(b[:-1], b[1:]))
+            strip_cost = lambda bb: max(cost[y0 // 16: -(-y1 // 16)].sum() for y0, y1 in bb if y1 > y0)
+            assert strip_cost(b) <= strip_cost(sharding.strip_bounds(h, n)) + 1e-9       # never worse than equal rows
+    # a frame whose top half is free (sky): the cuts move into the expensive half
+    b = sharding.strip_bounds_weighted(np.r_[np.zeros(64), np.ones(71)], 8, 2160)
+    assert b[0][1] >= 64 * 16 and max(y1 - y0 for y0, y1 in b[1:]) <= 10 * 16
+    s = torch.zeros((3, 5, 4), dtype=torch.int32)
+    s[..., 0] = 0x7FFFFFF0
+    s[..., 1] = torch.tensor(-(2 ** 31) + 5)          # end wrapped past 2^31: lifetime 21 ticks
+    assert sharding.band_costs_from_stamps(s).tolist() == [105.0, 105.0, 105.0]
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -69,7 +88,19 @@ def _worker(rank, world, port, out_path):
     reqs = sharding.gather_frames(mine, slots, async_op=True)
     for q in reqs:
         q.wait()
+    # cost-weighted strips: every rank contributes its strip's band costs, all ranks derive the same cuts
+    bounds = sharding.strip_bounds(H, world)
+    y0, y1 = bounds[rank]
+    local_cost = np.arange(y0 // 16, -(-y1 // 16), dtype=np.float64) ** 2 + 1.0    # stand-in for last frame's wave lifetimes
+    cost = sharding.exchange_band_costs(local_cost, y0, -(-H // 16))
+    assert np.array_equal(cost, np.arange(-(-H // 16), dtype=np.float64) ** 2 + 1.0)
+    wb = sharding.strip_bounds_weighted(cost, world, H)
+    assert wb[0][1] > bounds[0][1]                                               # the cheap top strip grows
+    y0, y1 = wb[rank]
+    full3 = torch.full((H, W, 4), -1.0) if rank == 0 else None
+    sharding.gather_strips(shade(synth.scene_sweep(W, H, cam, rows=(y0, y1))), wb, full3, dst=0)
     if rank == 0:
+        assert torch.equal(full3, got)
         np.savez(out_path, strips=got.numpy(), frames=torch.stack(slots).numpy())
     dist.barrier()
     dist.destroy_process_group()
