@@ -5,7 +5,9 @@ Each .npz holds the packed G-buffer planes, uniforms, lights, shadow map and the
 outputs: hdr_f64 (float64 NumPy oracle), hdr_c32 / ldr_c32 / srgb8_via_ldr_c32 (FP32 C
 oracle, the bit-exact target of the strict HIP kernels), hdr_dir_only_c32 (reference path
 only: directional lights, no extensions).  fxaa_101x70.npz: an R11G11B10F frame and its
-FXAA'd B8G8R8A8 sRGB image from both oracles."""
+FXAA'd B8G8R8A8 sRGB image from both oracles.  frame_chain_96x54.npz: the whole subpass chain of Frame::build on the
+sweep scene - lighting, sky, transparency resolve (hdr), tonemap (ldr R11G11B10F), FXAA (B8G8R8A8 sRGB) - with its
+sky parameters and accum / revealage inputs, from the FP32 C oracle."""
 import os
 import sys
 
@@ -49,4 +51,13 @@ if __name__ == '__main__':
     from test_oracle_kat import fxaa_test_image
     ldr = fxaa_test_image(70, 101, 3)
     np.savez_compressed(os.path.join(OUT, 'fxaa_101x70.npz'), ldr=ldr, srgb8_c32=co.fxaa(ldr), srgb8_f64=mo.fxaa(ldr))
+    # the whole chain of hdr-writing subpasses + tonemap + FXAA (mil_shade_frame + mil_fxaa) on the sweep fixture
+    from test_oracle_kat import transparency_test_inputs
+    z = np.load(os.path.join(OUT, 'sweep_96x54.npz'))
+    prm = synth.hosek_params_synthetic()
+    acc, rev = transparency_test_inputs(54, 96, seed=96)
+    hdr = co.transparency_resolve(acc, rev, co.sky_hosek(z['depth'], z['frame'], prm, z['hdr_c32'].copy()))
+    ldr = co.tonemap(hdr, 1)
+    np.savez_compressed(os.path.join(OUT, 'frame_chain_96x54.npz'), sky_params=prm, accum=acc, reveal=rev, hdr_c32=hdr,
+                        ldr_c32=ldr, swapchain_c32=co.fxaa(ldr))
     print('wrote fixtures to', OUT)

@@ -530,6 +530,28 @@ def test_shade_frame_strict_vs_oracle_chain(lp, coracle):
     assert bad.mean() < 1e-3
 
 
+def test_shade_frame_golden_fixture(lp):
+    """The committed whole-chain fixture: strict mil_shade_frame + mil_fxaa reproduce it (sky texels to the last ulp of
+    exp / pow / acos, everything else bit for bit); fast mode within 1 LSB of the swapchain image."""
+    z, g = np.load(os.path.join(GOLDEN, 'frame_chain_96x54.npz')), np.load(os.path.join(GOLDEN, 'sweep_96x54.npz'))
+    gb = {k: torch.from_numpy(g[k].view(np.int32) if g[k].dtype == np.uint32 else g[k]).to(DEV) for k in ('normal', 'albedo_occ', 'rough_metal', 'depth')}
+    sh = dict(light_view_proj=g['shadow_lvp'], map=torch.from_numpy(g['shadow_map']).to(DEV), bias=float(g['shadow_bias']))
+    ta, tr = torch.from_numpy(z['accum']).to(DEV), torch.from_numpy(z['reveal']).to(DEV)
+    args = (gb, g['frame'], g['dir_lights'], g['point_lights'], g['ambient'], sh)
+    kw = dict(sky=z['sky_params'], accum=ta, reveal=tr)
+    S = lighting.FLAG_STRICT
+    hdr = lp.shade_frame(*args, fmt=lighting.OUT_HDR, flags=S, **kw).cpu().numpy()
+    sky = g['depth'] >= 1
+    np.testing.assert_allclose(hdr, z['hdr_c32'], rtol=3e-7, atol=0)
+    assert_bits_equal(hdr[~sky], z['hdr_c32'][~sky], 'frame fixture, non-sky texels')
+    ldr = lp.shade_frame(*args, fmt=lighting.OUT_LDR, flags=S, **kw)
+    assert (ldr.cpu().numpy().view(np.uint32) != z['ldr_c32']).mean() < 2e-3
+    np.testing.assert_array_equal(lp.fxaa(torch.from_numpy(z['ldr_c32'].view(np.int32)).to(DEV), strict=True).cpu().numpy().view(np.uint32), z['swapchain_c32'])
+    fast = lp.fxaa(lp.shade_frame(*args, fmt=lighting.OUT_LDR, **kw)).cpu().numpy().view(np.uint32)
+    d = np.abs(channels(fast) - channels(z['swapchain_c32'])).max(-1)
+    assert (d > 1).mean() <= 1e-2                        # R11G11B10F rounding of a fast-mode value may flip a code; FXAA may flip a texel pick
+
+
 def test_shade_frame_4k_chain(lp):
     """The whole 4K frame: one launch + FXAA == the five-call chain, and the ldr image against the oracle on a band."""
     from test_oracle_kat import sky_test_params

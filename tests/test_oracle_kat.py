@@ -289,6 +289,19 @@ def test_fxaa_two_restatements_agree_and_strips(coracle):
     assert np.all(lin <= win.max((-1, -2)) + 1e-12) and np.all(lin >= win.min((-1, -2)) - 1e-12)
 
 
+def test_frame_chain_golden_fixture(coracle):
+    """The whole-chain fixture still comes out of the C oracle, and the float64 oracle agrees with it."""
+    z, g = np.load(os.path.join(GOLDEN, 'frame_chain_96x54.npz')), np.load(os.path.join(GOLDEN, 'sweep_96x54.npz'))
+    hdr = coracle.transparency_resolve(z['accum'], z['reveal'], coracle.sky_hosek(g['depth'], g['frame'], z['sky_params'], g['hdr_c32'].copy()))
+    np.testing.assert_array_equal(hdr.view(np.uint32), z['hdr_c32'].view(np.uint32))
+    np.testing.assert_array_equal(coracle.tonemap(hdr, 1), z['ldr_c32'])
+    np.testing.assert_array_equal(coracle.fxaa(z['ldr_c32']), z['swapchain_c32'])
+    h64 = mo.transparency_resolve(z['accum'], z['reveal'], mo.sky_hosek(g['depth'], g['frame'], z['sky_params'], g['hdr_f64']))
+    fin = np.isfinite(h64).all(-1)
+    assert (np.abs(h64 - hdr)[fin] > 1e-4 + 1e-4 * np.abs(h64)[fin]).mean() < 2e-3      # FP32 vs float64: a few grazing-angle texels
+    assert (g['depth'] >= 1).mean() > 0.2 and (z['reveal'] < 1).mean() > 0.05       # the fixture does exercise sky and resolve
+
+
 def test_fxaa_golden_fixture(coracle):
     z = np.load(os.path.join(GOLDEN, 'fxaa_101x70.npz'))
     np.testing.assert_array_equal(coracle.fxaa(z['ldr']), z['srgb8_c32'])
