@@ -98,7 +98,7 @@ typedef struct mil_point_light {
 } mil_point_light;
 
 /* E3: 3x3 PCF shadow on directional light 0.  `map` is DEVICE memory, size x size
- * floats, depth 0..1 as seen through light_view_proj (column-major, no w divide). */
+ * floats (size <= 16384), depth 0..1 as seen through light_view_proj (column-major, no w divide). */
 typedef struct mil_shadow {
     float light_view_proj[16];
     const float *map;

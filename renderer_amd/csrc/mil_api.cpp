@@ -385,7 +385,7 @@ static int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     if (n_point > c->max_point) return MIL_ERR_CAPACITY;
     if (n_point && !ex->point_lights) return MIL_ERR_BAD_ARG;
     const mil_shadow *sh = ex ? ex->shadow : nullptr;
-    if (sh && (!sh->map || sh->size == 0)) return MIL_ERR_BAD_ARG;
+    if (sh && (!sh->map || sh->size == 0 || sh->size > 16384u)) return MIL_ERR_BAD_ARG;   // 32-bit texel offsets in the taps
     if ((rc = set_device(c))) return rc;
 
     hipStream_t s = (hipStream_t)stream;

@@ -454,6 +454,22 @@ DEV ShadowTap shadow_tap(f3 P, const ShadeParams &p)
     t.zc = zr - p.shadow_bias;
     return t;
 }
+#if !MIL_STRICT
+// the two pixels of a lane at once: the same fma chains as shadow_coords (packed ops round like the scalar ones)
+DEV void shadow_tap2(const V3<v2f> &P, const ShadeParams &p, ShadowTap &ta, ShadowTap &tb)
+{
+    auto row = [&](int r) {
+        return fma_((v2f)(p.lvp[r]), P.x, fma_((v2f)(p.lvp[4 + r]), P.y, fma_((v2f)(p.lvp[8 + r]), P.z, (v2f)(p.lvp[12 + r]))));
+    };
+    const v2f u = fma_(row(0), (v2f)(0.5f), (v2f)(0.5f)), v = fma_(row(1), (v2f)(0.5f), (v2f)(0.5f)), zr = row(2);
+    const v2f S = (v2f)((float)p.shadow_size);
+    const v2f fu = __builtin_elementwise_floor(u * S), fv = __builtin_elementwise_floor(v * S), zc = zr - p.shadow_bias;
+    ta.inside = (u.x >= 0.0f && u.x <= 1.0f && v.x >= 0.0f && v.x <= 1.0f) && !(zr.x > 1.0f);
+    tb.inside = (u.y >= 0.0f && u.y <= 1.0f && v.y >= 0.0f && v.y <= 1.0f) && !(zr.y > 1.0f);
+    ta.tx = ta.inside ? (int)fu.x : 0; ta.ty = ta.inside ? (int)fv.x : 0; ta.zc = zc.x;
+    tb.tx = tb.inside ? (int)fu.y : 0; tb.ty = tb.inside ? (int)fv.y : 0; tb.zc = zc.y;
+}
+#endif
 struct __attribute__((packed, aligned(4))) Row3 { float a, b, c; };
 DEV float pcf_direct(const ShadowTap &t, const ShadeParams &p)
 {
@@ -463,9 +479,11 @@ DEV float pcf_direct(const ShadowTap &t, const ShadeParams &p)
     const bool border = t.tx < 1 || t.ty < 1 || t.tx > S - 2 || t.ty > S - 2;
     if (__builtin_amdgcn_ballot_w64(border) == 0) {
         // interior for every active lane: clamp-to-edge is the identity, a row of taps is 3 consecutive floats
-        const float *q = p.shadow_map + (size_t)(t.ty - 1) * S + (t.tx - 1);
+        const uint32_t o = (uint32_t)(t.ty - 1) * (uint32_t)S + (uint32_t)(t.tx - 1);     // < 2^28: the host caps the map at 16384^2
+        __builtin_assume(o < (1u << 28));
+        const float *q = p.shadow_map + o;
         Row3 r0, r1, r2;
-        __builtin_memcpy(&r0, q, 12); __builtin_memcpy(&r1, q + S, 12); __builtin_memcpy(&r2, q + 2 * (size_t)S, 12);
+        __builtin_memcpy(&r0, q, 12); __builtin_memcpy(&r1, q + (uint32_t)S, 12); __builtin_memcpy(&r2, q + 2u * (uint32_t)S, 12);
         cnt = (t.zc <= r0.a) + (t.zc <= r0.b) + (t.zc <= r0.c) + (t.zc <= r1.a) + (t.zc <= r1.b) + (t.zc <= r1.c) +
               (t.zc <= r2.a) + (t.zc <= r2.b) + (t.zc <= r2.c);
         return pcf_result(cnt);
@@ -748,8 +766,10 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
     const bool sh = EXT && p.has_shadow && p.n_dir > 0;
     v2f shadow = { 1.0f, 1.0f };
     if (sh) {
-        if (litA) shadow.x = pcf_direct(shadow_tap(f3{ q.P.x.x, q.P.y.x, q.P.z.x }, p), p);
-        if (litB) shadow.y = pcf_direct(shadow_tap(f3{ q.P.x.y, q.P.y.y, q.P.z.y }, p), p);
+        ShadowTap ta, tb;
+        shadow_tap2(q.P, p, ta, tb);
+        if (litA) shadow.x = pcf_direct(ta, p);
+        if (litB) shadow.y = pcf_direct(tb, p);
     }
     for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, sh && l == 0, r);   // fs_deferred_lighting.glsl:62-64
     if (EXT) {
@@ -1096,8 +1116,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         if (cnt) gather(0, ra, rb);       // stays in registers across the passes unless the list is longer than 64
 
         // E3 shadow term of one pixel (integer logic shared by both numeric modes)
-        auto shadow_px = [&](f3 P) -> float {
-            const ShadowTap st = shadow_tap(P, p);
+        auto shadow_px = [&](const ShadowTap &st) -> float {
             if (!staged) return pcf_direct(st, p);
             if (!st.inside) return 1.0f;
             int c9 = 0;
@@ -1123,7 +1142,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             f3 r = { 0.0f, 0.0f, 0.0f };
             if (ch == 0) {
                 float shadow = 1.0f;
-                if (do_shadow && litj) shadow = shadow_px(q.P);
+                if (do_shadow && litj) shadow = shadow_px(shadow_tap(q.P, p));
                 for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
             } else {
                 r = f3{ s_res[j * 64 + lane], s_res[256 + j * 64 + lane], s_res[512 + j * 64 + lane] };
@@ -1183,8 +1202,10 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             if (ch == 0) {
                 v2f shadow = { 1.0f, 1.0f };
                 if (do_shadow) {
-                    if (litA) shadow.x = shadow_px(f3{ q.P.x.x, q.P.y.x, q.P.z.x });
-                    if (litB) shadow.y = shadow_px(f3{ q.P.x.y, q.P.y.y, q.P.z.y });
+                    ShadowTap ta, tb;
+                    shadow_tap2(q.P, p, ta, tb);
+                    if (litA) shadow.x = shadow_px(ta);
+                    if (litB) shadow.y = shadow_px(tb);
                 }
                 for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
             } else {
