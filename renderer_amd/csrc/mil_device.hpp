@@ -322,7 +322,9 @@ DEV void setup_pixel(Px &q, const ShadeParams &, Pos pos, uint32_t u1, uint32_t 
 template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T LdotH, V3<T> col, T scale, V3<T> &res)
 {
     T x2 = NdotH * NdotH;
-    T k = q.alpha * rcp_(fma_(x2, q.am1, (T)1.0f));                      // alpha / ((1-x2) + x2*alpha^2)
+    // alpha / ((1-x2) + x2*alpha^2).  For a mirror-like texel (roughness byte <= 3) alpha^2 - 1 rounds to -1, the literal
+    // FP32 denominator is 0 at N.H = 1 and D_GGX is inf (in the reference's shader too); its true minimum is alpha^2
+    T k = q.alpha * rcp_(max_(fma_(x2, q.am1, (T)1.0f), q.a2));
     T sL = sqrt_(fma_(fma_(-q.a2, NdotL, NdotL), NdotL, q.a2));
     T den = fma_(NdotL, q.sV, q.NdotV * sL);                             // GGXV + GGXL
     T DV = (k * k) * ((0.5f / PI_LIT) * rcp_(den));                      // D * Vis
@@ -339,14 +341,16 @@ template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T Ld
 template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
     V3<T> H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
-    T rh = rsq_(dot3(H, H));
+    // L = -V (light straight behind the pixel as seen from the camera): H = 0 and normalize(H) is NaN in the literal
+    // shader; here |H|^2 is floored, N.H and L.H come out 0 and the term dies with N.L = 0 as it should
+    T rh = rsq_(max_(dot3(H, H), (T)(1e-30f)));
     eval_tail<T>(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), col, scale, res);
 }
 // |L| = 1 (point lights, normalised here):  |L+V|^2 = 2 + 2 L.V,  N.H = (N.L + N.V) / |L+V|,  L.H = (1 + L.V) / |L+V|
 template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
     T nl = dot3(q.N, L), lv = dot3(L, q.V);
-    T rh = rsq_(fma_((T)2.0f, lv, (T)2.0f));
+    T rh = rsq_(max_(fma_((T)2.0f, lv, (T)2.0f), (T)(1e-30f)));     // L = -V: see eval_light
     eval_tail<T>(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(fma_(lv, rh, rh)), col, scale, res);
 }
 

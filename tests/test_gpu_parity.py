@@ -600,3 +600,26 @@ def test_4k_properties(lp):
     strip['y_offset'] = y0
     fast_tolerance_ok(a[y0:y1].cpu().numpy(), planes_np(strip), frame, dl, pl, AMB, sh_np(sh), y_offset=y0,
                       full_height=h, max_bad_frac=1e-3)
+
+
+def test_8k_4096_lights_properties(lp):
+    """BASELINE.json configs[3] at full size (7680x4320, 4096 point lights, more than one culling chunk per tile):
+    culled == brute force bit for bit, strip-sharded (8 strips on 16-row cuts) == monolithic, fused sRGB8 == unfused."""
+    from renderer_amd import sharding
+    w, h = 7680, 4320
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=4096, shadow=2048)
+    a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    assert torch.isfinite(a).all() and torch.all(a[..., 3] == 1)
+    y0, y1 = 2048, 2048 + 544                                                # brute force on one strip through the sphere wall
+    strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+    strip['y_offset'] = y0
+    b = lp.light_ex(strip, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL)
+    assert torch.equal(b.view(torch.int32), a[y0:y1].view(torch.int32))
+    out = torch.empty_like(a)
+    for y0, y1 in sharding.strip_bounds(h, 8):
+        strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+        strip['y_offset'] = y0
+        lp.light_ex(strip, frame, dl, pl, AMB, sh, out=out[y0:y1])
+    assert torch.equal(out.view(torch.int32), a.view(torch.int32))
+    del out, b
+    assert torch.equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_SRGB8), lp.tonemap(a, lighting.OUT_SRGB8))
