@@ -413,6 +413,11 @@ def main():
                                                     hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                                     note='tools/probe/stream_probe.hip: the same four-plane access pattern with no arithmetic takes 43.6 us (6.09 TB/s), a float4 copy 41.6 us')
         del inp1
+        # side measurement: lighting + tonemap as ONE launch (hdr stays in registers; what mil_shade_frame does when the frame has
+        # no sky / transparency subpass): same output as the two-kernel step that `value` times
+        if not args.fused:
+            lf = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), True, args.flags)
+            res['extra']['headline_one_launch'] = dict(kernel='k_tiled+tonemap -> sRGB8', ms=round(lf, 4), mpix_s=round(px / lf / 1e3, 1))
         # side measurement: the reference's whole frame, G-buffer -> swapchain image (render/mod.rs:189-329: lighting, sky,
         # transparency resolve, tonemap, FXAA), as the five-call chain and as mil_shade_frame + mil_fxaa (hdr never stored)
         res['extra']['frame_4k_gbuffer_to_swapchain'] = frame_chain(torch, lighting, synth, lp, inp, max(args.steps, 20))
