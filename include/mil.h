@@ -129,7 +129,7 @@ typedef struct mil_extras {
 
 typedef struct mil_ctx mil_ctx;
 
-/* Context: owns a ring of staged uniform/light buffers sized at creation. */
+/* Context: owns a ring of staged uniform/light buffers sized at creation.  max_point_lights <= 65535. */
 int mil_create(mil_ctx **out, int device, uint32_t max_point_lights);
 void mil_destroy(mil_ctx *ctx);
 

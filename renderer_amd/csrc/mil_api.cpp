@@ -290,6 +290,7 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
 {
     if (!out) return MIL_ERR_BAD_ARG;
     *out = nullptr;
+    if (max_point_lights > 65535u) return MIL_ERR_BAD_ARG;   // tile lists hold 16-bit light indices
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return MIL_ERR_NO_DEVICE;
     mil_ctx *c = new (std::nothrow) mil_ctx();

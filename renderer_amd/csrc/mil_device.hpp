@@ -894,7 +894,7 @@ static __host__ __device__ __forceinline__ TiledLds tiled_lds(uint32_t n_point, 
     TiledLds l;
     const uint32_t cap = n_point < (uint32_t)CHUNK ? ((n_point + 63u) & ~63u) : (uint32_t)CHUNK;   // list entries (u16)
     l.list = 4096u;                                                   // after the 4 x 4 x 64 texel dwords
-    l.stash = l.list + ((cap * 2u + 15u) & ~15u);
+    l.stash = l.list + ((cap * 2u + 2u + 15u) & ~15u);              // + one dump entry behind the list (branch-free append)
     l.shadow = l.stash + (n_point > (uint32_t)CHUNK ? 768u * 4u : 0u);
     l.resolve = l.shadow + (stage ? (uint32_t)SH_CAP * 4u : 0u);
     l.per_wave = l.resolve + (resolve ? 2560u : 0u);                  // whole frame: 256 accum texels (8 B) + 256 revealage (2 B)
@@ -926,7 +926,6 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t n_chunks = p.n_point ? (p.n_point + CHUNK - 1) / CHUNK : 1;
     const uint32_t wpb = blockDim.x >> 6;               // waves (= tiles) per workgroup
     const bool do_shadow = p.has_shadow && p.n_dir > 0;
     const bool stage = do_shadow && p.shadow_lds;
@@ -1084,36 +1083,48 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         }
     }
 
-    uint32_t total = 0;
+    // Rounds: lights are culled in ascending order until they are exhausted or the LDS list (CHUNK entries) could
+    // overflow in the next 64-light step; the survivors are shaded; a tile that needed another round parks its partial
+    // sums in LDS and goes on culling where it stopped.  Nearly every tile takes one round whatever the light count.
+    uint32_t total = 0, next = 0;
+    bool first = true, last;
+    const uint32_t list_cap = p.n_point < (uint32_t)CHUNK ? ((p.n_point + 63u) & ~63u) : (uint32_t)CHUNK;
 #pragma unroll 1
-    for (uint32_t ch = 0; ch < n_chunks; ch++) {
-        // ---- 3. cull this chunk of lights into the wave's LDS list (ascending order) ----
-        const uint32_t base = ch * CHUNK, end = min(base + (uint32_t)CHUNK, p.n_point);
+    do {
+        // ---- 3. cull lights into the wave's LDS list (ascending order) ----
+        const uint32_t end = p.n_point;
         uint32_t cnt = 0;
         if (any_lit) {
-            v4f c = c_first;
-            if (ch > 0) { c = v4f{ 0.0f, 0.0f, 0.0f, 0.0f }; if (base + lane < end) c = cull[base + lane]; }
+            // 256 lights per trip: the four 16-byte records of a lane are requested together (clamped index instead of a
+            // branch), so one memory latency is paid per 256 lights, not per 64.  A trip starts only if its survivors
+            // are sure to fit the list, or if everything that is left fits.
+            uint32_t b0 = next;
 #pragma unroll 1
-            for (uint32_t b0 = base; b0 < end; b0 += 64) {
-                const uint32_t li = b0 + lane;
-                v4f cn = { 0.0f, 0.0f, 0.0f, 0.0f };
-                if (li + 64 < end) cn = cull[li + 64];                 // next step's records fly during this step
-                const bool pass = li < end && box_d2(c, lo, hi) < c.w * c.w;
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
-                if (pass) {
+            for (; b0 < end && (cnt + 256 <= list_cap || end - b0 <= list_cap - cnt); b0 += 256) {
+                v4f c4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) c4[u] = (u == 0 && first && b0 == 0) ? c_first : cull[min(b0 + 64 * u + lane, end - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {          // straight-line: rejected lanes write the dump entry behind the list
+                    const uint32_t li = b0 + 64 * u + lane;
+                    const bool pass = (li < end) & (box_d2(c4[u], lo, hi) < c4[u].w * c4[u].w);
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                     const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    s_list[pos] = (uint16_t)(li - base);
+                    s_list[pass ? pos : list_cap] = (uint16_t)li;
+                    cnt += (uint32_t)__builtin_popcountll(m);
                 }
-                cnt += (uint32_t)__builtin_popcountll(m);
-                c = cn;
             }
+            next = min(b0, end);
             __builtin_amdgcn_wave_barrier();
+        } else {
+            next = end;
         }
+        last = next >= end;
         total += cnt;
 
         // ---- 5. lane k <- record of list entry kb + k ----
         auto gather = [&](uint32_t kb, v4f &ga, v4f &gb) {
-            const uint32_t li = base + s_list[min(kb + lane, cnt - 1)];
+            const uint32_t li = s_list[min(kb + lane, cnt - 1)];
             ga = point_rec_a_v(p, li); gb = point_rec_b_v(p, li);
         };
         v4f ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
@@ -1144,7 +1155,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             Px q;
             setup_pixel(q, p, pixel_position(p, x, y, depth), u1, w2, u3);
             f3 r = { 0.0f, 0.0f, 0.0f };
-            if (ch == 0) {
+            if (first) {
                 float shadow = 1.0f;
                 if (do_shadow && litj) shadow = shadow_px(shadow_tap(q.P, p));
                 for (uint32_t l = 0; l < p.n_dir; l++) add_directional(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
@@ -1171,7 +1182,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 }
                 if (cnt > 64 && j < 3) gather(0, ra, rb);
             }
-            if (ch + 1 == n_chunks) {
+            if (last) {
                 if (p.has_ambient) add_ambient(q, p, w2, r);
                 if (inbj) emit_pixel<FMT, FRAME>(p, x, y, depth, r, s_resolve);
             } else {
@@ -1190,7 +1201,6 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             const v2f depth = { __uint_as_float(s_tex[(12 + ja) * 64 + lane]), __uint_as_float(s_tex[(13 + ja) * 64 + lane]) };
             const bool inA = xin && ya <= ylast, inB = xin && yb <= ylast;
             const bool litA = inA && (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
-            const bool last = ch + 1 == n_chunks;
             // occlusion 0 (cleared G-buffer, render/mod.rs:129-131: sky / background) multiplies every term of
             // fs_deferred_lighting.glsl:63 and of the extensions: the pixel is exactly 0.  When none of the
             // pass's 128 pixels is lit the wave writes the zeros and skips the shading altogether.
@@ -1203,7 +1213,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + p.y_offset), (float)(yb + p.y_offset) }, depth),
                                     u1, w2, u3);
             V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
-            if (ch == 0) {
+            if (first) {
                 v2f shadow = { 1.0f, 1.0f };
                 if (do_shadow) {
                     ShadowTap ta, tb;
@@ -1253,8 +1263,9 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             }
         }
 #endif
-        __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next chunk only after these reads were issued
-    }
+        __builtin_amdgcn_wave_barrier();   // the list is rewritten by the next round only after these reads were issued
+        first = false;
+    } while (!last);
     if (p.tile_counts && lane == 0) p.tile_counts[tyi * p.tiles_x + txi] = total;
     if (p.tile_stamps && lane == 0) {                    // diagnostics: wave lifetime and placement
         uint32_t *st = p.tile_stamps + 4 * (size_t)(tyi * p.tiles_x + txi);

@@ -267,6 +267,30 @@ def test_culled_equals_brute_force(lp, strict):
             assert 0 < counts.float().mean().item() < 0.6 * n                # the culling does cull
 
 
+def test_tile_list_overflow_rounds(lp, coracle):
+    """More lights reach a tile than its LDS list holds (1024): the tile is shaded in rounds, partial sums parked in LDS.
+    Every light reaches every pixel here (radius 60), 1500 and 2300 of them: still == brute force bit for bit in both
+    modes and == the C oracle in strict mode."""
+    for n in (1500, 2300):
+        gb, frame, dl, pl, sh = make_scene('sweep', 80, 48, n_point=n, shadow=64)
+        pl = pl.copy()
+        pl[:, 3] = 60.0
+        pl[:, 7] = 0.01
+        counts = lp.tile_counts(gb)
+        a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+        lp.tile_counts(gb, enable=False)
+        lit_tiles = (((gb['albedo_occ'] >> 24) & 0xFF) != 0).view(3, 16, 5, 16).any(3).any(1)
+        assert torch.all(counts[lit_tiles] == n) and counts.max().item() == n
+        b = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL)
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        S = lighting.FLAG_STRICT
+        ref = coracle.shade(*planes_np(gb), frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh))
+        assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=S).cpu().numpy(), ref, f'overflow rounds strict {n}')
+        assert_bits_equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=S | lighting.FLAG_NO_CULL).cpu().numpy(), ref, f'brute strict {n}')
+        one = lp.shade_frame(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_LDR)
+        assert torch.equal(one, lp.tonemap(a, lighting.OUT_LDR))
+
+
 @pytest.mark.parametrize('strict', [False, True])
 def test_extensions_vanish_when_disabled(lp, strict):
     gb, frame, dl, _, _ = make_scene('sweep', 160, 90)
