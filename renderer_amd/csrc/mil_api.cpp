@@ -30,6 +30,7 @@ struct Slot {
     hipEvent_t staged = nullptr; // upload of this slot's content finished (recorded on the copy stream)
     bool used = false;
     uint32_t n_dir = 0, n_point = 0;
+    uint64_t gen = 0;            // bumped whenever new content is staged into this slot
 };
 
 } // namespace
@@ -40,12 +41,16 @@ struct mil_ctx {
     size_t slot_bytes = 0;
     Slot ring[RING];
     int next = 0, cur = -1;      // cur: slot holding the most recently staged content
+    uint64_t gen = 0;
     uint8_t *scratch = nullptr;  // host: the content of this call, built before it is compared with slot `cur`
     hipStream_t copy_stream = nullptr;
     uint8_t *lut = nullptr; // device: lut11 then lut10
     uint32_t *tile_counts = nullptr;
     uint32_t *tile_stamps = nullptr;
     uint32_t tune = 0;
+    uint16_t row_order[MIL_MAX_ROW_ORDER];   // last computed K2 row order and what it was computed from (order_rows)
+    uint8_t row_key[176];
+    bool row_key_valid = false;
     uint32_t tonemap_rows = 0;   // K4 rows per lane (env MIL_TONEMAP_ROWS; tuning only)
     uint32_t k1_rows = 1;   // K1 pixels per lane: 1 or 4 (env MIL_K1_ROWS overrides; tuning only)
     int last_hip = 0;
@@ -107,6 +112,26 @@ int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, co
                  uint32_t n_point, bool strict, hipStream_t s, mil::ShadeParams &p, Slot *&slot_out)
 {
     const size_t dir_b = (size_t)MIL_MAX_DIR_LIGHTS * 32, pt_b = (size_t)c->max_point * 32;
+    // Static lights (the common case frame to frame): the inputs equal the raw copies the current slot holds - the
+    // prepared arrays derive from those, so nothing is rebuilt, compared or uploaded (one memcmp of 32 bytes per light).
+    if (c->cur >= 0 && (n_dir > MIL_DIR_INLINE || n_point > 0)) {
+        Slot &cs = c->ring[c->cur];
+        bool same = cs.n_dir == n_dir && cs.n_point == n_point && (!n_point || !memcmp(cs.host + 2 * dir_b, pl, (size_t)n_point * 32));
+        for (uint32_t i = 0; same && i < n_dir; i++) same = !memcmp(cs.host + 32 * i, &dl[i], 28);      // the pad word is not part of the light
+        if (same) {
+            for (uint32_t i = 0; i < n_dir && i < MIL_DIR_INLINE; i++)
+                memcpy(p.dir_inline[i], cs.host + (strict ? 0 : dir_b) + 32 * i, 32);
+            HIP_TRY(c, hipStreamWaitEvent(s, cs.staged, 0));
+            p.dir_raw = (const float4 *)cs.dev;
+            p.dir_prep = (const float4 *)(cs.dev + dir_b);
+            p.point_raw = (const float4 *)(cs.dev + 2 * dir_b);
+            p.point_prep = (const float4 *)(cs.dev + 2 * dir_b + pt_b);
+            p.point_cull = (const float4 *)(cs.dev + 2 * dir_b + 2 * pt_b);
+            p.n_dir = n_dir; p.n_point = n_point;
+            slot_out = &cs;
+            return MIL_OK;
+        }
+    }
     uint8_t *h = c->scratch;
     float *h_dir_raw = (float *)h, *h_dir_prep = (float *)(h + dir_b);
     float *h_pt_raw = (float *)(h + 2 * dir_b), *h_pt_prep = (float *)(h + 2 * dir_b + pt_b);
@@ -158,6 +183,7 @@ int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, co
                 memcpy(sl->host + 2 * dir_b + 2 * pt_b, h + 2 * dir_b + 2 * pt_b, np / 2);
             }
             sl->n_dir = n_dir; sl->n_point = n_point;
+            sl->gen = ++c->gen;
             if (nd) HIP_TRY(c, hipMemcpyAsync(sl->dev, sl->host, dir_b + nd, hipMemcpyHostToDevice, c->copy_stream));
             if (np) HIP_TRY(c, hipMemcpyAsync(sl->dev + 2 * dir_b, sl->host + 2 * dir_b, 2 * pt_b + np / 2, hipMemcpyHostToDevice, c->copy_stream));
             HIP_TRY(c, hipEventRecord(sl->staged, c->copy_stream));
@@ -219,10 +245,21 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
 // Scheduling heuristic of the tiled kernel (speed only; any permutation is correct): tile rows are launched
 // in descending order of the number of point lights whose bounding sphere can project onto them, ties from the
 // bottom of the frame upwards, so that the expensive rows are in flight early and the launch ends on cheap ones.
-void order_rows(mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_point_light *pl, uint32_t n_point)
+struct RowOrderKey { float view[16], proj[16]; uint32_t height, y_offset, n_point; float res_y; uint64_t lights_gen; };
+void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_point_light *pl, uint32_t n_point)
 {
     const uint32_t R = p.tiles_y;
     if (R > MIL_MAX_ROW_ORDER) return;
+    // same lights (slot generation), camera and strip as the last call: same order
+    RowOrderKey key;
+    memset(&key, 0, sizeof(key));
+    memcpy(key.view, f->view, 64); memcpy(key.proj, f->projection, 64);
+    key.height = p.height; key.y_offset = p.y_offset; key.n_point = n_point; key.res_y = p.res_y; key.lights_gen = lights ? lights->gen : 0;
+    static_assert(sizeof(c->row_key) >= sizeof(RowOrderKey), "row order key storage");
+    if (c->row_key_valid && !memcmp(c->row_key, &key, sizeof(key))) {
+        memcpy(p.row_order, c->row_order, sizeof(p.row_order));
+        return;
+    }
     uint32_t w[MIL_MAX_ROW_ORDER];
     for (uint32_t i = 0; i < R; i++) w[i] = 0;
     const float *V = f->view, *P = f->projection;      // column-major
@@ -253,6 +290,9 @@ void order_rows(mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_p
     for (uint32_t lvl = wmax + 1; lvl-- > 0;)
         for (uint32_t i = R; i-- > 0;)
             if (w[i] == lvl) p.row_order[n++] = (uint16_t)i;
+    memcpy(c->row_order, p.row_order, sizeof(p.row_order));
+    memcpy(c->row_key, &key, sizeof(key));
+    c->row_key_valid = true;
 }
 
 int finish(mil_ctx *c, Slot *sl, hipStream_t s)
@@ -428,7 +468,7 @@ static int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     const bool strict = (flags & MIL_FLAG_STRICT) != 0;
     const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
     if (tiled) {
-        order_rows(p, frame, ex ? ex->point_lights : nullptr, n_point);
+        order_rows(c, slot, p, frame, ex ? ex->point_lights : nullptr, n_point);
         p.tile_counts = c->tile_counts;
         p.tile_stamps = c->tile_stamps;
         if (strict) mil::strict::launch_tiled((int)fmt, p, whole, s);
