@@ -29,23 +29,39 @@ SWZ = {c: i for s in ('xyzw', 'rgba', 'stpq') for i, c in enumerate(s)}
 
 
 # --------------------------------------------------------------------------------------------- source handling
-def preprocess(path, seen=None):
-    """#include expansion (the reference uses vulkano-shaders' textual include), comments stripped."""
-    seen = seen or set()
+def preprocess(path, seen=None, macros=None):
+    """#include expansion (the reference uses vulkano-shaders' textual include), comments stripped, object-like
+    #define macros substituted, #ifdef / #ifndef / #endif honoured."""
+    seen = seen if seen is not None else set()
+    macros = macros if macros is not None else {}
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
     src = re.sub(r'//[^\n]*', '', src)
-    out = []
+    out, live = [], [True]
     for line in src.split('\n'):
-        m = re.match(r'\s*#include\s+"([^"]+)"', line)
+        m = re.match(r'\s*#\s*(\w+)\s*(.*)', line)
         if m:
-            inc = os.path.join(os.path.dirname(path), m.group(1))
-            if inc not in seen:
-                seen.add(inc)
-                out.append(preprocess(inc, seen))
-        elif re.match(r'\s*#(version|extension)', line):
+            d, rest = m.group(1), m.group(2).strip()
+            if d in ('ifdef', 'ifndef'):
+                live.append(live[-1] and ((rest in macros) == (d == 'ifdef')))
+            elif d == 'endif':
+                live.pop()
+            elif not live[-1]:
+                pass
+            elif d == 'include':
+                inc = os.path.join(os.path.dirname(path), rest.strip('"'))
+                if inc not in seen:
+                    seen.add(inc)
+                    out.append(preprocess(inc, seen, macros))
+            elif d == 'define':
+                name, _, body = rest.partition(' ')
+                macros[name] = body.strip()
+            elif d not in ('version', 'extension'):
+                raise SyntaxError(f'preprocessor directive #{d} is not in the subset')
             continue
-        else:
+        if live[-1]:
+            for _ in range(4):                                     # nested object-like macros
+                line = re.sub(r'\b(' + '|'.join(map(re.escape, macros)) + r')\b', lambda mm: macros[mm.group(1)], line) if macros else line
             out.append(line)
     return '\n'.join(out)
 
@@ -366,6 +382,7 @@ class Shader:
         for ty, name in self.p.outs:
             g[name] = np.zeros((n_frag, VEC[ty]), F32)
         self.mask = None
+        self.g = g
         self.exec_block(self.p.funcs['main'][2], [g, {}])
         return {name: np.broadcast_to(g[name], (n_frag, VEC[ty])).copy() for ty, name in self.p.outs}
 
@@ -585,8 +602,10 @@ class Shader:
         ret_ty, params, body = self.p.funcs[name]
         local = {}
         for (pty, pname, pq), a in zip(params, args):
-            local[pname] = a if (isinstance(a, (dict, list, tuple)) or is_int(a)) else to_rt(a)
-            if pty in VEC and not isinstance(local[pname], (dict, list, tuple)) and not is_int(local[pname]) and local[pname].shape[1] == 1 and VEC[pty] > 1:
+            if 'out' in pq and 'inout' not in pq:
+                a = None if pty not in VEC else np.zeros((1, VEC[pty]), F32)
+            local[pname] = a if (a is None or callable(a) or isinstance(a, (dict, list, tuple)) or is_int(a)) else to_rt(a)
+            if pty in VEC and hasattr(local[pname], 'shape') and local[pname].shape[1] == 1 and VEC[pty] > 1:
                 local[pname] = np.repeat(local[pname], VEC[pty], 1)
             if is_int(local[pname]) and pty in VEC:
                 local[pname] = to_rt(local[pname])
@@ -596,10 +615,17 @@ class Shader:
             self.exec_block(body, [env[0], local])
         except Ret:
             pass
-        if saved is not None and self.mask is not saved:
+        if self.mask is not saved:
             raise NotImplementedError('return inside a divergent branch of a called function')
-        self.mask = saved
-        return self.ret_val
+        ret = self.ret_val
+        for (pty, pname, pq), node in zip(params, arg_nodes):     # copy-out of out / inout parameters
+            if 'out' in pq or 'inout' in pq:
+                self.assign(node, '=', local[pname], env)
+        return ret
+
+    def call_function(self, name, *args):
+        """Run one function of the shader on its own (e.g. PositionFromDepth); uniforms as set by the last run()."""
+        return self.call(name, [np.asarray(a, F32) if not is_int(a) else a for a in args], [None] * len(args), [self.g])
 
     # built-ins (conventions: module docstring)
     @staticmethod

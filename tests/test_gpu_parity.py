@@ -647,3 +647,40 @@ def test_8k_4096_lights_properties(lp):
     assert torch.equal(out.view(torch.int32), a.view(torch.int32))
     del out, b
     assert torch.equal(lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_SRGB8), lp.tonemap(a, lighting.OUT_SRGB8))
+
+
+def test_strict_kernels_vs_executed_reference_shaders(lp):
+    """tests/golden/glsl_reference.npz holds what the reference's own GLSL files produce (executed by oracle/glsl_exec.py
+    in the development container).  The strict kernels reproduce it: lighting, tonemap, resolve and FXAA bit for bit
+    (NaN == NaN), the sky to the last ulp of exp / pow / acos."""
+    ref = np.load(os.path.join(GOLDEN, 'glsl_reference.npz'))
+
+    def same(a, b):
+        a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+        return bool(np.all((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))))
+    gbs = {}
+    for name in ('sweep_96x54', 'noise_64x36'):
+        g = np.load(os.path.join(GOLDEN, name + '.npz'))
+        gb = {k: torch.from_numpy(g[k].view(np.int32) if g[k].dtype == np.uint32 else g[k]).to(DEV) for k in ('normal', 'albedo_occ', 'rough_metal', 'depth')}
+        gbs[name] = (gb, g)
+        got = lp.light_directional(gb, g['frame'], g['dir_lights'], strict=True).cpu().numpy()
+        assert same(got, ref['hdr_' + name.split('_')[0]]), name
+    gb, g = gbs['sweep_96x54']
+    assert same(lp.light_directional(gb, g['frame'], g['dir_lights'][:1], strict=True).cpu().numpy(), ref['hdr_sweep_1light'])
+    # tonemap: ACESFilm of the shader, packed by the oracle's R11G11B10F encoder (the attachment encode is the driver's)
+    from oracle import coracle
+    coracle.build()
+    ti = torch.from_numpy(ref['tonemap_in'].reshape(-1, 1, 4).copy()).to(DEV)
+    mine = np.array([coracle.pack_r11g11b10f(*t[:3]) for t in ref['tonemap_out']], np.uint32)
+    np.testing.assert_array_equal(lp.tonemap(ti, lighting.OUT_LDR, strict=True).cpu().numpy().view(np.uint32).reshape(-1), mine)
+    # resolve (shader + blend) and sky on the executed lighting output
+    hdr = torch.from_numpy(ref['hdr_sweep'].copy()).to(DEV)
+    ta, tr = torch.from_numpy(ref['resolve_accum']).to(DEV), torch.from_numpy(ref['resolve_reveal']).to(DEV)
+    assert same(lp.transparency_resolve(ta, tr, hdr.clone(), strict=True).cpu().numpy(), ref['resolve_hdr'])
+    sky = lp.sky_hosek(gb, g['frame'], ref['sky_params'], hdr.clone(), strict=True).cpu().numpy()
+    np.testing.assert_allclose(sky, ref['sky_hdr'], rtol=3e-7, atol=0)
+    # FXAA: the shader's float colour through the swapchain's sRGB8 encode
+    f = np.load(os.path.join(GOLDEN, 'fxaa_101x70.npz'))
+    enc = mo.encode_b8g8r8a8_srgb(ref['fxaa_color'][..., :3].astype(np.float64))
+    got = lp.fxaa(torch.from_numpy(f['ldr'].view(np.int32)).to(DEV), strict=True).cpu().numpy().view(np.uint32)
+    np.testing.assert_array_equal(got, enc)
