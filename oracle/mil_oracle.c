@@ -4,11 +4,15 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the
  * product (renderer_amd/, libmil.so) never does.
  *
- * PARITY UNPINNED: the reference has no tests, fixtures or golden images for
- * its render path and cannot be built in this image (no rustc, no GLSL
- * compiler, no Vulkan ICD).  This file is pinned by the hand-derived known
- * answers in tests/test_oracle_kat.py and by agreement with the independent
- * float64 restatement oracle/mil_oracle.py.
+ * PARITY: the reference has no tests, fixtures or golden images for its render
+ * path and cannot be built in this image (no rustc, no GLSL compiler, no Vulkan
+ * ICD).  The shader arithmetic below is pinned to the reference's own source:
+ * oracle/glsl_exec.py executes the .glsl files and this file reproduces their
+ * output bit for bit (tests/test_glsl_reference.py, tests/golden/glsl_reference.npz).
+ * UNPINNED: texel format conversions, GLSL built-in precision / evaluation order
+ * (the rules listed below), blending, and the build-defined extensions.  Also
+ * pinned by the hand-derived known answers in tests/test_oracle_kat.py and by the
+ * independent float64 restatement oracle/mil_oracle.py.
  *
  * Build (oracle/Makefile): gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp.
  * With contraction off and SSE arithmetic every operation below is one

@@ -4,12 +4,15 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``renderer_amd/`` may import this
 module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
 ``cpu_baseline`` leg do, and there only as the checker.
 
-PARITY UNPINNED: the reference holds no test, fixture or golden image for its
-render path and neither its Rust host nor its GLSL
-can be built in this image (no rustc, no GLSL compiler, no Vulkan ICD).  What
-pins this oracle instead: the hand-derived known answers in
-``tests/test_oracle_kat.py`` and agreement with the independent FP32 C
-restatement in ``oracle/mil_oracle.c``.
+PARITY: the reference holds no test, fixture or golden image for its render path
+ and neither its Rust host nor its GLSL can be built in
+this image (no rustc, no GLSL compiler, no Vulkan ICD).  The shader arithmetic is
+pinned to the reference's own source: ``oracle/glsl_exec.py`` executes the .glsl
+files and ``tests/test_glsl_reference.py`` compares (the FP32 C oracle bit for bit,
+this float64 one to FP32 rounding).  UNPINNED: texel format conversions, GLSL
+built-in precision, blending, cgmath (driver / third-party, restated from their
+published definitions) and the build-defined extensions.  Also pinned by the
+hand-derived known answers in ``tests/test_oracle_kat.py``.
 
 Every function cites the reference lines (relative to /root/reference/) it
 follows.  Arithmetic is float64 on the float32-quantised inputs, so this is the
