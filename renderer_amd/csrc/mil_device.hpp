@@ -322,8 +322,9 @@ DEV void setup_pixel(Px &q, const ShadeParams &, Pos pos, uint32_t u1, uint32_t 
 template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T LdotH, V3<T> col, T scale, V3<T> &res)
 {
     T x2 = NdotH * NdotH;
-    // alpha / ((1-x2) + x2*alpha^2).  For a mirror-like texel (roughness byte <= 3) alpha^2 - 1 rounds to -1, the literal
-    // FP32 denominator is 0 at N.H = 1 and D_GGX is inf (in the reference's shader too); its true minimum is alpha^2
+    // alpha / ((1-x2) + x2*alpha^2), the denominator rewritten as x2*(alpha^2-1) + 1.  For a mirror-like texel (roughness
+    // byte <= 3) alpha^2 - 1 rounds to -1 and the rewritten form is 0 at N.H = 1 (the literal form gives alpha^2 there):
+    // clamped to that true minimum
     T k = q.alpha * rcp_(max_(fma_(x2, q.am1, (T)1.0f), q.a2));
     T sL = sqrt_(fma_(fma_(-q.a2, NdotL, NdotL), NdotL, q.a2));
     T den = fma_(NdotL, q.sV, q.NdotV * sL);                             // GGXV + GGXL

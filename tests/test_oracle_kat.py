@@ -1,6 +1,6 @@
 """Pins the CPU oracles (oracle/mil_oracle.py float64, oracle/mil_oracle.c FP32) with the
 hand-derived known answers of SURVEY.md 8(c) — the reference itself holds no golden
-vector for this path; tests/test_glsl_reference.py pins the oracles to the executed shader text) — and checks the two
+vector for this path (tests/test_glsl_reference.py pins the oracles to the executed shader text) — and checks the two
 restatements agree."""
 import os
 
