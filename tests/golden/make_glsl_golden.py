@@ -40,9 +40,13 @@ def frag_coord(w, h, y_offset=0):
     return np.stack([xx.reshape(-1) + 0.5, yy.reshape(-1) + y_offset + 0.5, np.zeros(w * h), np.ones(w * h)], 1).astype(F32)
 
 
-def lighting(z, n_lights=None):
-    """fs_deferred_lighting.glsl on the planes of a committed fixture; returns (hdr, shader instance, world positions)."""
-    h, w = z['depth'].shape
+def lighting(z, n_lights=None, rows=None):
+    """fs_deferred_lighting.glsl on the planes of a committed fixture (rows = (y0, y1): only that strip's fragments, with
+    their global gl_FragCoord and the full-frame resolution); returns (hdr, shader instance)."""
+    full_h, w = z['depth'].shape
+    y0, y1 = rows or (0, full_h)
+    h = y1 - y0
+    z = {k: (z[k][y0:y1] if k in ('normal', 'albedo_occ', 'rough_metal', 'depth') else z[k]) for k in z.files}
     n, a, r = (z[k].reshape(-1) for k in ('normal', 'albedo_occ', 'rough_metal'))
     inputs = {
         'normal_l_model': np.stack([unorm(n & 0x3FF, 10), unorm((n >> 10) & 0x3FF, 10), unorm((n >> 20) & 0x3FF, 10), unorm(n >> 30, 2)], 1),
@@ -53,9 +57,9 @@ def lighting(z, n_lights=None):
     dl = z['dir_lights'] if n_lights is None else z['dir_lights'][:n_lights]
     uni = {'frame_matrix_data': frame_uniforms(z['frame']),
            'lights_ubo': dict(lights=[dict(direction=l[0:3], intensity=l[3], color=l[4:7]) for l in dl]),
-           'push_constants': dict(resolution=np.array([w, h], F32), light_count=len(dl))}
+           'push_constants': dict(resolution=np.array([w, full_h], F32), light_count=len(dl))}
     sh = glsl_exec.Shader(SHADERS + 'fs_deferred_lighting.glsl')
-    hdr = sh.run(w * h, uniforms=uni, frag_coord=frag_coord(w, h), inputs=inputs)['hdr'].reshape(h, w, 4)
+    hdr = sh.run(w * h, uniforms=uni, frag_coord=frag_coord(w, h, y0), inputs=inputs)['hdr'].reshape(h, w, 4)
     return hdr, sh
 
 
@@ -68,6 +72,7 @@ def main():
     out['hdr_noise'], _ = lighting(noise)
     out['hdr_sweep_1light'], _ = lighting(sweep, 1)
     out['hdr_sweep_0lights'], _ = lighting(sweep, 0)
+    out['hdr_sweep_rows16_32'], _ = lighting(sweep, rows=(16, 32))      # a strip: global gl_FragCoord.y, full-frame resolution
     # ---- tonemap: ACESFilm on assorted hdr values (the attachment's R11G11B10F encode is the driver's)
     rng = np.random.RandomState(5)
     hdr_s = np.concatenate([np.array([0, 1e-8, 1e-4, 0.01, 0.18, 0.5, 1, 2, 10, 1e3, 6.5e4, 1e9], F32), (rng.rand(500) ** 4 * 20).astype(F32)])

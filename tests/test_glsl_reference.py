@@ -36,6 +36,9 @@ def test_lighting_shader(ref, coracle):
     assert bits_equal(ref['hdr_sweep_1light'], coracle.shade(*planes(sw), sw['frame'], sw['dir_lights'][:1]))
     assert bits_equal(ref['hdr_sweep_0lights'], coracle.shade(*planes(sw), sw['frame'], sw['dir_lights'][:0]))
     assert np.all(ref['hdr_sweep_0lights'][..., :3] == 0) and np.all(ref['hdr_sweep'][..., 3] == 1)
+    # a strip of the frame: the shader sees global gl_FragCoord.y and the full resolution = the oracle's y_offset / full_height
+    strip = coracle.shade(*[p[16:32] for p in planes(sw)], sw['frame'], sw['dir_lights'], y_offset=16, full_height=54)
+    assert bits_equal(ref['hdr_sweep_rows16_32'], strip) and bits_equal(ref['hdr_sweep_rows16_32'], ref['hdr_sweep'][16:32])
     # the float64 restatement agrees with the executed shader to FP32 rounding
     a = mo.shade(*planes(sw), sw['frame'], sw['dir_lights'])
     fin = np.isfinite(a).all(-1)
