@@ -332,6 +332,38 @@ def test_light_staging_ring_and_cache(lp, coracle):
     assert_bits_equal(a, coracle.shade(*planes_np(gb), frame, many), '9 directional lights')
 
 
+def test_host_caches_follow_camera_strip_and_stream_changes(lp):
+    """The host caches (staged lights recognised from the input arrays, K2 row order per lights / camera / strip) must
+    never change a result: same lights under a moving camera, different strips, alternating streams and a light edited
+    in place, each culled launch == its brute-force twin; contexts come and go."""
+    from renderer_amd import sharding
+    w, h = 192, 112
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=90, shadow=64)
+    pl = pl.copy()
+    streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+    torch.cuda.synchronize()
+    for i in range(8):
+        cam = sharding.orbit_camera(i % 5, 5, w, h)
+        g2 = synth.scene_sweep(w, h, cam, device=DEV)
+        fr = cam.frame_matrix_data()
+        if i == 5:
+            pl[3, 0:3] += 0.5                                                 # edited in place: same pointer, new content
+        st = streams[i % 2]
+        y0, y1 = (0, h) if i % 3 else (32, 80)
+        strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in g2.items()}
+        strip['y_offset'] = y0
+        a = lp.light_ex(strip, fr, dl, pl, AMB, sh, stream=st)
+        b = lp.light_ex(strip, fr, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL, stream=st)
+        st.synchronize()
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32)), i
+    for _ in range(6):
+        lp2 = lighting.LightingPass(0, 128)
+        a = lp2.light_ex(gb, frame, dl, pl, AMB, sh)
+        lp2.sync()
+        assert torch.equal(a.view(torch.int32), lp.light_ex(gb, frame, dl, pl, AMB, sh).view(torch.int32))
+        lp2.close()
+
+
 def test_count_pairs(lp, coracle):
     gb, frame, dl, pl, _ = make_scene('sweep', 160, 90, n_point=100)
     _, pairs = coracle.shade(*planes_np(gb), frame, dl[:0], point_lights=pl, return_pairs=True)
