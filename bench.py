@@ -347,9 +347,13 @@ def main():
     dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
                       pipelined=(args.pipelined and world == 1), gather=strips)
     dt_gather = None
+    gather_error = None
     if world > 1 and not strips:       # the same frames, each gathered to GPU 0 (xGMI-bound)
-        dt_gather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
-                                 pipelined=False, gather=True)
+        try:
+            dt_gather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
+                                     pipelined=False, gather=True)
+        except Exception as e:          # the headline measurement above must still be reported
+            gather_error = f'{type(e).__name__}: {e}'[:300]
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -392,6 +396,8 @@ def main():
                            streams=('1 (serial)' if (not args.pipelined or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),
                roofline=primary, roofline_other=other)
+    if gather_error is not None:
+        res['config']['gather_to_gpu0'] = dict(error=gather_error)
     if dt_gather is not None:
         res['config']['gather_to_gpu0'] = dict(value=round(world * args.steps * px / dt_gather / 1e6, 1), unit='Mpix/s',
                                                ms_per_step=round(dt_gather / args.steps * 1e3, 4),
