@@ -558,6 +558,30 @@ def test_shade_frame_largest_lds_carve(lp):
         assert torch.equal(one.view(torch.int32), hdr.view(torch.int32)), flags
 
 
+def test_shade_frame_pitched_and_misaligned_transparency_inputs(lp):
+    """accum / revealage as views into larger images: pitch > width, column offsets that leave the revealage pointer only
+    2-byte aligned (the LDS-DMA staging needs 4: the kernel must fall back to direct loads), odd widths, tiny frames."""
+    from test_oracle_kat import sky_test_params, transparency_test_inputs
+    prm = sky_test_params()
+    for (w, h), off in [((160, 96), 0), ((160, 96), 2), ((160, 96), 3), ((67, 35), 1), ((2, 3), 0), ((1, 1), 5), ((18, 17), 4)]:
+        gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=20, shadow=64)
+        acc, rev = transparency_test_inputs(h, w, seed=w + off)
+        big_a = torch.zeros((h, w + 11, 4), dtype=torch.float16, device=DEV)
+        big_r = torch.ones((h, w + 11), dtype=torch.float16, device=DEV)
+        big_a[:, off:off + w] = torch.from_numpy(acc).to(DEV)
+        big_r[:, off:off + w] = torch.from_numpy(rev).to(DEV)
+        va, vr = big_a[:, off:off + w], big_r[:, off:off + w]
+        ta, tr = va.contiguous(), vr.contiguous()
+        for flags in (0, lighting.FLAG_STRICT):
+            ref = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=lighting.OUT_HDR, flags=flags)
+            got = lp.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=va, reveal=vr, fmt=lighting.OUT_HDR, flags=flags)
+            assert torch.equal(got.view(torch.int32), ref.view(torch.int32)), (w, h, off, flags)
+            hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=flags)
+            st = bool(flags & lighting.FLAG_STRICT)
+            lp.sky_hosek(gb, frame, prm, hdr, strict=st); lp.transparency_resolve(va, vr, hdr, strict=st)
+            assert torch.equal(got.view(torch.int32), hdr.view(torch.int32)), (w, h, off, flags, 'chain')
+
+
 def test_shade_frame_strict_vs_oracle_chain(lp, coracle):
     """Strict whole-frame launch against the C oracle's subpass chain (shade -> sky -> resolve -> tonemap), and the fast
     launch against the float64 chain."""
