@@ -566,8 +566,9 @@ def test_shade_frame_pitched_and_misaligned_transparency_inputs(lp):
     for (w, h), off in [((160, 96), 0), ((160, 96), 2), ((160, 96), 3), ((67, 35), 1), ((2, 3), 0), ((1, 1), 5), ((18, 17), 4)]:
         gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=20, shadow=64)
         acc, rev = transparency_test_inputs(h, w, seed=w + off)
-        big_a = torch.zeros((h, w + 11, 4), dtype=torch.float16, device=DEV)
-        big_r = torch.ones((h, w + 11), dtype=torch.float16, device=DEV)
+        pad = 12 if off == 2 else 11                     # off 2 / pad 12: even pitch, 4-byte aligned views -> the LDS-DMA path with pitch > width
+        big_a = torch.zeros((h, w + pad, 4), dtype=torch.float16, device=DEV)
+        big_r = torch.ones((h, w + pad), dtype=torch.float16, device=DEV)
         big_a[:, off:off + w] = torch.from_numpy(acc).to(DEV)
         big_r[:, off:off + w] = torch.from_numpy(rev).to(DEV)
         va, vr = big_a[:, off:off + w], big_r[:, off:off + w]
