@@ -624,6 +624,15 @@ DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res, float
         __builtin_nontemporal_store(encode_ldr<FMT>(res.x, res.y, res.z, p.lut11, p.lut10), (uint32_t *)p.out + o);
     }
 }
+// A black pixel (unlit tile) stored through pointers the caller fetched earlier: its encodings are constants
+// (ACES(0) = 0: R11G11B10F code 0, sRGB8 0xFF000000), so no uniform is read at the store.
+template <int FMT>
+DEV void store_zero(void *out, uint32_t out_pitch, uint32_t x, uint32_t y)
+{
+    const size_t o = (size_t)y * out_pitch + x;
+    if (FMT == FMT_HDR) __builtin_nontemporal_store(v4f{ 0.0f, 0.0f, 0.0f, 1.0f }, (v4f *)out + o);
+    else __builtin_nontemporal_store(FMT == FMT_LDR ? 0u : 0xFF000000u, (uint32_t *)out + o);
+}
 // Whole-frame launch (FRAME, mil_shade_frame): what the later hdr-writing subpasses of the reference's render pass do
 // to this pixel happens in registers before the one store - sky where the depth is still the clear value
 // (render/mod.rs:221-226), then the transparency resolve blend (render/mod.rs:282-294), then the tonemap/pack of FMT
@@ -928,12 +937,23 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wpb = blockDim.x >> 6;               // waves (= tiles) per workgroup
-    const bool do_shadow = p.has_shadow && p.n_dir > 0;
-    const bool stage = do_shadow && p.shadow_lds;
+    // Everything the first phase reads, requested together: uniforms come through an opaque pointer (see kernarg_params),
+    // so read one by one behind branches they cost a scalar-memory round trip each - six before the first texel was
+    // requested, six more in an unlit tile's store path; a sky tile's wave spent most of its 2.7 us waiting on them.
+    const uint32_t k_n_point = p.n_point, k_has_shadow = p.has_shadow, k_n_dir = p.n_dir, k_shadow_lds = p.shadow_lds;
+    const uint32_t k_tune = p.tune, k_tiles_x = p.tiles_x, k_tiles_y = p.tiles_y, k_width = p.width, k_height = p.height, k_pitch = p.pitch;
+    const uint32_t k_resolve_dma = FRAME ? p.resolve_dma : 0u, k_has_sky = FRAME ? p.has_sky : 0u;
+    const uint32_t *const k_albedo = p.albedo;
+    const uint16_t *const k_accum = FRAME ? p.accum : nullptr;
+    uint32_t *const k_stamps = p.tile_stamps;
+    asm volatile("" :: "s"(k_n_point), "s"(k_has_shadow), "s"(k_n_dir), "s"(k_shadow_lds), "s"(k_tune), "s"(k_tiles_x), "s"(k_tiles_y),
+                 "s"(k_width), "s"(k_height), "s"(k_pitch), "s"(k_resolve_dma), "s"(k_has_sky), "s"(k_albedo), "s"(k_accum), "s"(k_stamps));
+    const bool do_shadow = k_has_shadow && k_n_dir > 0;
+    const bool stage = do_shadow && k_shadow_lds;
     // whole frame with a resolve: the tile's accum / revealage texels ride the LDS-DMA with the G-buffer planes, so their
     // latency is not exposed at the store (dword granularity: the host sets resolve_dma when pitches / width allow it)
-    const bool rdma = FRAME && p.accum && p.resolve_dma;
-    const TiledLds L = tiled_lds(p.n_point, stage, rdma);
+    const bool rdma = FRAME && k_accum && k_resolve_dma;
+    const TiledLds L = tiled_lds(k_n_point, stage, rdma);
     unsigned char *s_wave = s_raw + wv * L.per_wave;
     uint32_t *s_tex = (uint32_t *)s_wave;               // [plane: normal, albedo, rm, depth][j][lane]
     uint16_t *s_list = (uint16_t *)(s_wave + L.list);
@@ -945,22 +965,22 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     // tile row (a workgroup reads whole 256-byte row segments).  The ROWS are visited in the order the host
     // computed (mil_api.cpp order_rows): rows that many point lights reach first, cheap rows last, so the
     // expensive waves are not the tail of the launch.  Nothing depends on the order but speed.
-    const uint32_t bpr = (p.tiles_x + wpb - 1) / wpb, blk = blockIdx.x;
-    const uint32_t ri = blk / bpr, tyi = (p.tune & 1u) || p.tiles_y > MIL_MAX_ROW_ORDER ? ri : (uint32_t)p.row_order[ri];
+    const uint32_t bpr = (k_tiles_x + wpb - 1) / wpb, blk = blockIdx.x;
+    const uint32_t ri = blk / bpr, tyi = (k_tune & 1u) || k_tiles_y > MIL_MAX_ROW_ORDER ? ri : (uint32_t)p.row_order[ri];
     const uint32_t txi = (blk - ri * bpr) * wpb + wv;
-    if (txi >= p.tiles_x) return;                       // whole wave; nothing below synchronises across waves
-    const uint64_t t_start = p.tile_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
+    if (txi >= k_tiles_x) return;                       // whole wave; nothing below synchronises across waves
+    const uint64_t t_start = k_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
 
     // ---- 1. HBM -> LDS, coordinates clamped (not branched) so the loads are straight-line ----
     const uint32_t x = txi * TILE + (lane & 15u), y0 = tyi * TILE + (lane >> 4);
-    const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
-    const bool xin = x < p.width;
+    const uint32_t xc = min(x, k_width - 1), ylast = k_height - 1;
+    const bool xin = x < k_width;
     {
         uint32_t i[4];       // texel offsets fit 30 bits (checked on the host): scalar plane base + one 32-bit lane offset per row
 #pragma unroll
-        for (int j = 0; j < 4; j++) { i[j] = min(y0 + 4 * j, ylast) * p.pitch + xc; __builtin_assume(i[j] < (1u << 30)); }
+        for (int j = 0; j < 4; j++) { i[j] = min(y0 + 4 * j, ylast) * k_pitch + xc; __builtin_assume(i[j] < (1u << 30)); }
 #pragma unroll
-        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.albedo + i[j]), (lptr_t)(s_tex + (4 + j) * 64), 4, 0, 0);
+        for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(k_albedo + i[j]), (lptr_t)(s_tex + (4 + j) * 64), 4, 0, 0);
         if (rdma) {
             uint32_t *dst = (uint32_t *)(s_wave + L.resolve);
 #pragma unroll
@@ -980,8 +1000,13 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         // The albedo/occlusion plane goes first: a tile without a lit pixel (sky: half of Scene A) writes its zeros and
         // never fetches the other three planes (12 of its 16 B/px); lit tiles pay one more LDS-DMA round trip, which
         // the VALU-bound phase hides (-5 % on the headline frame; MIL_TUNE bit 32 restores the single round).
-        if (!(p.tune & 32u)) {
-            const bool early_depth = FRAME && p.has_sky;     // a sky texel is told by its depth
+        if (!(k_tune & 32u)) {
+            const bool early_depth = FRAME && k_has_sky;     // a sky texel is told by its depth
+            // what an unlit tile's store path reads, fetched while the LDS-DMA is in flight
+            void *const e_out = p.out;
+            const uint32_t e_out_pitch = p.out_pitch;
+            uint32_t *const e_counts = p.tile_counts;
+            asm volatile("" :: "s"(e_out), "s"(e_out_pitch), "s"(e_counts));
             if (early_depth) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
@@ -993,17 +1018,19 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             if (__builtin_amdgcn_ballot_w64(any) == 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (xin && (y0 + 4 * j) <= ylast)
-                        emit_pixel<FMT, FRAME>(p, x, y0 + 4 * j, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
-                if (p.tile_counts && lane == 0) p.tile_counts[tyi * p.tiles_x + txi] = 0;
-                if (p.tile_stamps && lane == 0) {
-                    uint32_t *st = p.tile_stamps + 4 * (size_t)(tyi * p.tiles_x + txi);
+                    if (xin && (y0 + 4 * j) <= ylast) {
+                        if (FRAME) emit_pixel<FMT, FRAME>(p, x, y0 + 4 * j, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+                        else store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j);
+                    }
+                if (e_counts && lane == 0) e_counts[tyi * k_tiles_x + txi] = 0;
+                if (k_stamps && lane == 0) {
+                    uint32_t *st = k_stamps + 4 * (size_t)(tyi * k_tiles_x + txi);
                     st[0] = (uint32_t)t_start; st[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); st[2] = 0; st[3] = 0;
                 }
                 return;
             }
         }
-        if (!(FRAME && p.has_sky) || (p.tune & 32u))
+        if (!(FRAME && k_has_sky) || (k_tune & 32u))
 #endif
         {
 #pragma unroll
