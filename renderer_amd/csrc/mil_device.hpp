@@ -637,10 +637,8 @@ DEV void store_zero(void *out, uint32_t out_pitch, uint32_t x, uint32_t y)
 // to this pixel happens in registers before the one store - sky where the depth is still the clear value
 // (render/mod.rs:221-226), then the transparency resolve blend (render/mod.rs:282-294), then the tonemap/pack of FMT
 // (render/mod.rs:297-309).  hdr is a transient attachment in the reference (pbr/mod.rs:76-95); here it never exists.
-template <int FMT, bool FRAME>
-DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f3 res, const uint32_t *tile = nullptr)
+DEV v4f frame_value(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f3 res, const uint32_t *tile)
 {
-    if (!FRAME) { store_pixel<FMT>(p, x, y, res); return; }
     v4f h = { res.x, res.y, res.z, 1.0f };
     if (p.has_sky) {
         const bool sky = depth >= MIL_SKY_DEPTH;
@@ -671,7 +669,22 @@ DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f
         if (__builtin_amdgcn_ballot_w64(!resolve_untouched(a, r)) != 0) h = resolve_blend(a, r, h);
 #endif
     }
+    return h;
+}
+template <int FMT, bool FRAME>
+DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f3 res, const uint32_t *tile = nullptr)
+{
+    if (!FRAME) { store_pixel<FMT>(p, x, y, res); return; }
+    const v4f h = frame_value(p, x, y, depth, res, tile);
     store_pixel<FMT>(p, x, y, f3{ h.x, h.y, h.z }, h.w);
+}
+// the same store through pointers fetched earlier (see k_tiled's unlit tiles)
+template <int FMT>
+DEV void store_pixel_to(void *out, uint32_t out_pitch, const uint8_t *lut11, const uint8_t *lut10, uint32_t x, uint32_t y, v4f h)
+{
+    const size_t o = (size_t)y * out_pitch + x;
+    if (FMT == FMT_HDR) __builtin_nontemporal_store(h, (v4f *)out + o);
+    else __builtin_nontemporal_store(encode_ldr<FMT>(h.x, h.y, h.z, lut11, lut10), (uint32_t *)out + o);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1006,7 +1019,8 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             void *const e_out = p.out;
             const uint32_t e_out_pitch = p.out_pitch;
             uint32_t *const e_counts = p.tile_counts;
-            asm volatile("" :: "s"(e_out), "s"(e_out_pitch), "s"(e_counts));
+            const uint8_t *const e_lut11 = (FRAME && FMT == FMT_SRGB8_VIA_LDR) ? p.lut11 : nullptr, *const e_lut10 = (FRAME && FMT == FMT_SRGB8_VIA_LDR) ? p.lut10 : nullptr;
+            asm volatile("" :: "s"(e_out), "s"(e_out_pitch), "s"(e_counts), "s"(e_lut11), "s"(e_lut10));
             if (early_depth) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
@@ -1016,12 +1030,20 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll
             for (int j = 0; j < 4; j++) any |= xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
             if (__builtin_amdgcn_ballot_w64(any) == 0) {
+                if (FRAME) {        // sky / resolve of the four pixels first (their uniforms are read once), then the stores
+                    v4f h[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (xin && (y0 + 4 * j) <= ylast) {
-                        if (FRAME) emit_pixel<FMT, FRAME>(p, x, y0 + 4 * j, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
-                        else store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j);
-                    }
+                    for (int j = 0; j < 4; j++)
+                        if (xin && (y0 + 4 * j) <= ylast)
+                            h[j] = frame_value(p, x, y0 + 4 * j, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j, h[j]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j);
+                }
                 if (e_counts && lane == 0) e_counts[tyi * k_tiles_x + txi] = 0;
                 if (k_stamps && lane == 0) {
                     uint32_t *st = k_stamps + 4 * (size_t)(tyi * k_tiles_x + txi);
