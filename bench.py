@@ -171,6 +171,31 @@ def frame_chain(torch, lighting, synth, lp, inp, n):
                 mpix_s=round(px / o / 1e3, 1), passes='2 dir + PCF + 256 point + ambient, sky on 49 % of the texels, resolve over 1/6')
 
 
+def accumulate_burst(torch, synth, lp, inp, n, n_frag):
+    """mil_transparency_accumulate over n_frag fragments (one full-screen translucent layer at 4K), the frame's two directional
+    lights: 52 B read + 20 B written per fragment."""
+    fr = synth.transparent_fragments(n_frag, seed=7)
+    sets = [{k: torch.from_numpy(v).to(lp.device) for k, v in fr.items()} for _ in range(2)]
+    acc = [torch.empty((n_frag, 4), dtype=torch.float32, device=lp.device) for _ in range(2)]
+    rev = [torch.empty((n_frag,), dtype=torch.float32, device=lp.device) for _ in range(2)]
+
+    def one(i):
+        lp.transparency_accumulate(sets[i % 2], inp['frame'], inp['dl'], accum=acc[i % 2], reveal=rev[i % 2])
+    for i in range(5):
+        one(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(n):
+        one(i)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    b = 72 * n_frag
+    return dict(kernel='k_accumulate', fragments=n_frag, ms=round(ms, 4), mfrag_s=round(n_frag / ms / 1e3, 1), algorithmic_bytes=b,
+                hbm_GBs=round(b / ms / 1e6, 1), hbm_frac=round(b / ms / 1e6 / HBM_PEAK_GBS, 4))
+
+
 def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0, pipelined=True, gather=True):
     """Returns seconds for `steps` steps [max over ranks]."""
     from renderer_amd import sharding
@@ -427,6 +452,8 @@ def main():
         # side measurement: the reference's whole frame, G-buffer -> swapchain image (render/mod.rs:189-329: lighting, sky,
         # transparency resolve, tonemap, FXAA), as the five-call chain and as mil_shade_frame + mil_fxaa (hdr never stored)
         res['extra']['frame_4k_gbuffer_to_swapchain'] = frame_chain(torch, lighting, synth, lp, inp, max(args.steps, 20))
+        # side measurement: the accumulate draw's fragment shader over one full-screen translucent layer
+        res['extra']['transparency_accumulate_4k_layer'] = accumulate_burst(torch, synth, lp, inp, max(args.steps, 20), px)
     if not args.no_cpu and world == 1:
         res['cpu_baseline'] = cpu_baseline(inp)
     print(json.dumps(res))

@@ -177,6 +177,30 @@ int mil_transparency_resolve(mil_ctx *ctx, const void *accum, uint32_t accum_pit
                              uint32_t reveal_pitch_px, uint32_t width, uint32_t height, float *hdr,
                              uint32_t hdr_pitch_px, uint32_t flags, void *stream);
 
+/* The fragments of the transparency accumulate draw (render/mod.rs:229-281), one record per rasterised fragment of
+ * the translucent objects that passed the depth test, as four DEVICE planes holding what the rasteriser and the texture
+ * units hand the fragment shader (shaders/fs_mcguire13_accumulation.glsl:4-8, 91-98, 123). */
+typedef struct mil_transparent_fragments {
+    const float *position_depth;   /* float4: in_wsPosition.xyz, gl_FragCoord.z */
+    const float *normal_opacity;   /* float4: in_normal.xyz (interpolated, NOT normalised), opacity = material_data.opacity * texel (:96) */
+    const float *albedo_roughness; /* float4: albedo = material_data.albedo_color * texel (:91), roughness = material_data.roughness * texel (:93) */
+    const float *metallic;         /* float:  material_data.metallic * texel (:94) */
+    uint32_t count;                /* < 2^30; 0 = nothing to do */
+} mil_transparent_fragments;
+
+/* NEXT ROW (second half).  The fragment shader of the transparency accumulate draw,
+ * shaders/fs_mcguire13_accumulation.glsl:100-126 with specular() / diffuse() of inc_brdf.glsl:34-47, evaluated over a
+ * fragment list (rasterisation, texturing and the blend stay with the caller's raster pipeline or OIT builder):
+ *   lighting = sum_i (diffuse(albedo) + specular(..) * color_i * NdotL_i)     no intensity, no occlusion, roughness unclamped
+ *   accum_i  = vec4(lighting * opacity, opacity) * w10(gl_FragCoord.z, opacity),   reveal_i = opacity
+ * the values the blend state of render/mcguire13/mod.rs:57-84 adds into accum (ONE, ONE) and multiplies into reveal
+ * (ZERO, ONE_MINUS_SRC_ALPHA).  accum: DEVICE float4 per fragment, reveal: DEVICE float per fragment.  lights / push as in
+ * mil_light_directional (the same lights UBO is bound, render/mod.rs:252); only push->light_count is read. */
+int mil_transparency_accumulate(mil_ctx *ctx, const mil_transparent_fragments *fragments,
+                                const mil_frame_matrix_data *frame, const mil_directional_light *lights,
+                                const mil_push_constants *push, float *accum, float *reveal, uint32_t flags,
+                                void *stream);
+
 /* Lighting with the extensions, optionally fused with the tonemap (valid only when
  * nothing else writes hdr in between, unlike the reference's sky/transparency
  * subpasses, render/pbr/mod.rs:420-434).  `out` is float4 per pixel for

@@ -121,3 +121,18 @@ def transparency_resolve(accum_f16, reveal_f16, hdr, nthreads=0):
                                     ctypes.c_int(w), ctypes.c_int(h), _p(hdr, ctypes.c_float), ctypes.c_int(w),
                                     ctypes.c_int(nthreads))
     return hdr
+
+
+def transparency_accumulate(pos_z, nrm_op, alb_rough, metallic, camera_position, dir_lights, nthreads=0):
+    """oracle.mil_oracle.transparency_accumulate in FP32: four fragment planes ((n, 4) x 3, (n,)) -> accum (n, 4), reveal (n,)."""
+    f = ctypes.c_float
+    pos_z, nrm_op, alb_rough = (np.ascontiguousarray(a, np.float32).reshape(-1, 4) for a in (pos_z, nrm_op, alb_rough))
+    metallic = np.ascontiguousarray(metallic, np.float32).reshape(-1)
+    n = metallic.shape[0]
+    assert pos_z.shape[0] == nrm_op.shape[0] == alb_rough.shape[0] == n
+    cam = np.ascontiguousarray(camera_position, np.float32).reshape(3)
+    dl = np.ascontiguousarray(dir_lights, np.float32).reshape(-1, 8)
+    accum, reveal = np.empty((n, 4), np.float32), np.empty(n, np.float32)
+    lib().milo_transparency_accumulate(_p(pos_z, f), _p(nrm_op, f), _p(alb_rough, f), _p(metallic, f), ctypes.c_int(n), _p(cam, f),
+                                       _p(dl, f), ctypes.c_int(dl.shape[0]), _p(accum, f), _p(reveal, f), ctypes.c_int(nthreads))
+    return accum, reveal

@@ -75,16 +75,9 @@ static inline float V_SmithGGXCorrelated(float roughness, float NdotV, float Ndo
     return 0.5f / (GGXV + GGXL);
 }
 
-/* inc_brdf.glsl:49-63 light(), with specular() :34-43, fresnel() :25-32, diffuse() :45-47 inlined */
-static inline v3 brdf_light(v3 N, v3 L, v3 V, v3 lightColor, float roughness, v3 albedo, float metallic)
+/* inc_brdf.glsl:34-43 specular(), with fresnel() / F_Schlick :25-32 inlined (the vec3 h argument is unused) */
+static inline v3 brdf_specular(float roughness, v3 albedo, float metallic, float NdotV, float NdotL, float NdotH, float LdotH)
 {
-    v3 Hs = { L.x + V.x, L.y + V.y, L.z + V.z };
-    v3 H = normalize3(Hs);
-    float NdotV = clampf(dot3(N, V), 0.0001f, 1.0f);
-    float NdotL = clampf(dot3(N, L), 0.0f, 1.0f);
-    float NdotH = clampf(dot3(N, H), 0.0f, 1.0f);
-    float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
-
     float om = 1.0f - metallic;
     v3 F0 = { 0.04f * om + albedo.x * metallic, 0.04f * om + albedo.y * metallic, 0.04f * om + albedo.z * metallic };
     float D = D_GGX(roughness, NdotH);
@@ -95,6 +88,21 @@ static inline v3 brdf_light(v3 N, v3 L, v3 V, v3 lightColor, float roughness, v3
     v3 F = { F0.x + (f90 - F0.x) * pw, F0.y + (f90 - F0.y) * pw, F0.z + (f90 - F0.z) * pw };
     float DV = D * Vis;
     v3 spec = { DV * F.x, DV * F.y, DV * F.z };
+    return spec;
+}
+
+/* inc_brdf.glsl:49-63 light(), with diffuse() :45-47 inlined */
+static inline v3 brdf_light(v3 N, v3 L, v3 V, v3 lightColor, float roughness, v3 albedo, float metallic)
+{
+    v3 Hs = { L.x + V.x, L.y + V.y, L.z + V.z };
+    v3 H = normalize3(Hs);
+    float NdotV = clampf(dot3(N, V), 0.0001f, 1.0f);
+    float NdotL = clampf(dot3(N, L), 0.0f, 1.0f);
+    float NdotH = clampf(dot3(N, H), 0.0f, 1.0f);
+    float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
+
+    float om = 1.0f - metallic;
+    v3 spec = brdf_specular(roughness, albedo, metallic, NdotV, NdotL, NdotH, LdotH);
     v3 diff = { albedo.x / PI_LIT, albedo.y / PI_LIT, albedo.z / PI_LIT };
     /* color = diffuse*(1-metallic) + mix(specular, specular*albedo, metallic)   :60 */
     v3 color = { diff.x * om + (spec.x * om + (spec.x * albedo.x) * metallic),
@@ -417,6 +425,59 @@ void milo_transparency_resolve(const uint16_t *accum, int accum_pitch_px, const 
             for (int c = 0; c < 3; c++) o[c] = (half_dec(a[c]) / den) * om + o[c] * r;
             o[3] = r * om + o[3] * r;
         }
+}
+
+/*
+ * NEXT ROW f-2, second half: the fragment shader of the transparency ACCUMULATE draw,
+ * renderer/shaders/fs_mcguire13_accumulation.glsl:90-127 (drawn at render/mod.rs:229-281), over a list of
+ * fragments.  What the rasteriser and the texture units hand the shader arrives as four planes:
+ *   pos_z      float4  in_wsPosition.xyz, gl_FragCoord.z
+ *   nrm_op     float4  in_normal.xyz (interpolated, not normalised), opacity  = material_data.opacity   * texel  (:96)
+ *   alb_rough  float4  albedo.rgb = material_data.albedo_color * texel (:91), roughness = material_data.roughness * texel (:93)
+ *   metallic   float   material_data.metallic * texel (:94)
+ * Out, per fragment: accum = vec4(Ci, ai) * w10(zi, ai) (:121-125), reveal = ai (:126): the values the blend
+ * stage (mcguire13/mod.rs:57-84) adds into the RGBA16F / multiplies into the R16F attachment.
+ * Unlike light() there is no NdotL on the diffuse term, no intensity, no occlusion, and roughness is NOT
+ * clamped before it is squared (:104): roughness = 0 makes D * V = 0 * inf = NaN wherever N.L = 0, as in the shader.
+ * lights: n_dir records of 8 floats {direction.xyz, intensity, color.xyz, pad}; cam: cameraPosition.
+ */
+void milo_transparency_accumulate(const float *pos_z, const float *nrm_op, const float *alb_rough, const float *metallic,
+                                  int count, const float *cam, const float *lights, int n_dir, float *accum,
+                                  float *reveal, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < count; i++) {
+        const float *pz = pos_z + 4 * (size_t)i, *no = nrm_op + 4 * (size_t)i, *ar = alb_rough + 4 * (size_t)i;
+        v3 albedo = { ar[0], ar[1], ar[2] };
+        float roughness = ar[3], met = metallic[i], opacity = no[3];
+        roughness = roughness * roughness;                                   /* :104 */
+        v3 nrm = { no[0], no[1], no[2] }, N = normalize3(nrm);               /* :106 */
+        v3 Vd = { cam[0] - pz[0], cam[1] - pz[1], cam[2] - pz[2] }, V = normalize3(Vd); /* :107 */
+        v3 lighting = { 0.0f, 0.0f, 0.0f };
+        for (int l = 0; l < n_dir; l++) {                                    /* :110-119 */
+            const float *r = lights + 8 * (size_t)l;
+            v3 L = { r[0], r[1], r[2] };
+            v3 Hs = { L.x + V.x, L.y + V.y, L.z + V.z }, H = normalize3(Hs);
+            float NdotV = clampf(dot3(N, V), 0.0001f, 1.0f);
+            float NdotL = clampf(dot3(N, L), 0.0f, 1.0f);
+            float NdotH = clampf(dot3(N, H), 0.0f, 1.0f);
+            float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
+            v3 spec = brdf_specular(roughness, albedo, met, NdotV, NdotL, NdotH, LdotH);
+            /* lighting += diffuse(..) + specular(..) * color * NdotL */
+            lighting.x = lighting.x + (albedo.x / PI_LIT + (spec.x * r[4]) * NdotL);
+            lighting.y = lighting.y + (albedo.y / PI_LIT + (spec.y * r[5]) * NdotL);
+            lighting.z = lighting.z + (albedo.z / PI_LIT + (spec.z * r[6]) * NdotL);
+        }
+        float f = 1.0f - pz[3];                                              /* w10, :84-87 */
+        float w = opacity * fmaxf(0.01f, ((3000.0f * f) * f) * f);
+        float *a = accum + 4 * (size_t)i;
+        a[0] = (lighting.x * opacity) * w; a[1] = (lighting.y * opacity) * w; a[2] = (lighting.z * opacity) * w;
+        a[3] = opacity * w;
+        reveal[i] = opacity;
+    }
 }
 
 int milo_max_threads(void)

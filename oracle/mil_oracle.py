@@ -438,3 +438,42 @@ def transparency_resolve(accum_f16, reveal_f16, hdr):
     out[..., :3] = src * (1.0 - r)[..., None] + hdr[..., :3] * r[..., None]
     out[..., 3] = r * (1.0 - r) + hdr[..., 3] * r
     return out
+
+
+# --------------------------------------------------------------------------
+# NEXT ROW f-2, second half: the fragment shader of the transparency accumulate draw over a fragment list
+# (renderer/shaders/fs_mcguire13_accumulation.glsl:90-127; draw render/mod.rs:229-281).  Planes as in
+# oracle/mil_oracle.c milo_transparency_accumulate: pos_z = (in_wsPosition, gl_FragCoord.z), nrm_op = (in_normal,
+# opacity), alb_rough = (albedo, roughness), metallic; the material factor x texel products (:91-96) are the caller's.
+# --------------------------------------------------------------------------
+def transparency_accumulate(pos_z, nrm_op, alb_rough, metallic, camera_position, dir_lights, want_cond=False):
+    """want_cond: also return sum |specular term| x the conditioning of D_GGX w.r.t. NdotH, scaled like accum (see brdf_light)."""
+    pos_z, nrm_op, alb_rough = (np.asarray(a, np.float64).reshape(-1, 4) for a in (pos_z, nrm_op, alb_rough))
+    metallic = np.asarray(metallic, np.float64).reshape(-1)
+    cam = np.asarray(camera_position, np.float64).reshape(3)
+    albedo, opacity = alb_rough[:, :3], nrm_op[:, 3]
+    alpha = alb_rough[:, 3] ** 2                                     # :104 (no clamp, unlike fs_deferred_lighting.glsl:51)
+    N, V = _normalize(nrm_op[:, :3]), _normalize(cam - pos_z[:, :3])
+    m = metallic[:, None]
+    lighting, cond_bound = np.zeros_like(albedo), np.zeros_like(albedo)
+    for l in np.asarray(dir_lights, np.float64).reshape(-1, 8):      # :110-119
+        L = np.broadcast_to(l[0:3], N.shape)
+        H = _normalize(L + V)
+        NdotV, NdotL = np.clip(_dot(N, V), 0.0001, 1.0), np.clip(_dot(N, L), 0.0, 1.0)
+        NdotH, LdotH = np.clip(_dot(N, H), 0.0, 1.0), np.clip(_dot(L, H), 0.0, 1.0)
+        F0 = 0.04 * (1.0 - m) + albedo * m
+        k = alpha / ((1.0 - NdotH * NdotH) + (NdotH * alpha) ** 2)
+        D = k * k * (1.0 / PI_LITERAL)
+        a2 = alpha * alpha
+        Vis = 0.5 / (NdotL * np.sqrt((NdotV - a2 * NdotV) * NdotV + a2) + NdotV * np.sqrt((NdotL - a2 * NdotL) * NdotL + a2))
+        f90 = np.clip(_dot(F0, np.full(3, 50.0 * 0.33)), 0.0, 1.0)
+        F = F0 + (f90[:, None] - F0) * ((1.0 - LdotH) ** 5)[:, None]
+        spec = (D * Vis)[:, None] * F * l[4:7] * NdotL[:, None]
+        lighting = lighting + (albedo / PI_LITERAL + spec)
+        cond_bound += np.abs(spec) * (4.0 * NdotH * NdotH * np.abs(1.0 - a2) / ((1.0 - NdotH * NdotH) + (NdotH * alpha) ** 2))[:, None]
+    f = 1.0 - pos_z[:, 3]
+    w = opacity * np.maximum(0.01, 3000.0 * f * f * f)               # w10, :84-87
+    accum = np.concatenate([lighting * opacity[:, None], opacity[:, None]], 1) * w[:, None]
+    if want_cond:
+        return accum, opacity.copy(), np.concatenate([cond_bound * (opacity * w)[:, None], np.zeros((len(w), 1))], 1)
+    return accum, opacity.copy()

@@ -578,6 +578,51 @@ int mil_transparency_resolve(mil_ctx *c, const void *accum, uint32_t accum_pitch
     return finish(c, nullptr, (hipStream_t)stream);
 }
 
+int mil_transparency_accumulate(mil_ctx *c, const mil_transparent_fragments *fr, const mil_frame_matrix_data *frame,
+                                const mil_directional_light *lights, const mil_push_constants *push, float *accum,
+                                float *reveal, uint32_t flags, void *stream)
+{
+    if (!c || !fr || !frame || !push) return MIL_ERR_BAD_ARG;
+    if (push->light_count > MIL_MAX_DIR_LIGHTS) return MIL_ERR_TOO_MANY_LIGHTS;
+    if (fr->count == 0) return MIL_OK;                                   // no translucent fragment this frame
+    if (fr->count >= (1u << 30)) return MIL_ERR_BAD_ARG;
+    if (!fr->position_depth || !fr->normal_opacity || !fr->albedo_roughness || !fr->metallic || !accum || !reveal) return MIL_ERR_BAD_ARG;
+    if (push->light_count && !lights) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    mil::AccumParams p;
+    memset(&p, 0, sizeof(p));
+    p.pos_z = (const float4 *)fr->position_depth; p.nrm_op = (const float4 *)fr->normal_opacity;
+    p.alb_rough = (const float4 *)fr->albedo_roughness; p.metallic = fr->metallic;
+    p.accum = (float4 *)accum; p.reveal = reveal; p.count = fr->count; p.n_dir = push->light_count;
+    memcpy(p.cam, frame->camera_position, 12);
+    for (uint32_t i = 0; i < p.n_dir && i < MIL_DIR_INLINE; i++) memcpy(p.dir_inline[i], &lights[i], 28);
+    // Beyond the inline records the raw array is read from a staged slot: the one the lighting call of this frame staged
+    // when it holds the same directional lights (the reference binds one lights UBO to both draws, render/mod.rs:252)
+    Slot *slot = nullptr;
+    if (p.n_dir > MIL_DIR_INLINE) {
+        if (c->cur >= 0 && c->ring[c->cur].n_dir == p.n_dir) {
+            Slot &cs = c->ring[c->cur];
+            bool same = true;
+            for (uint32_t i = 0; same && i < p.n_dir; i++) same = !memcmp(cs.host + 32 * i, &lights[i], 28);
+            if (same) {
+                HIP_TRY(c, hipStreamWaitEvent(s, cs.staged, 0));
+                slot = &cs;
+                p.dir_raw = (const float4 *)cs.dev;
+            }
+        }
+        if (!slot) {
+            mil::ShadeParams sp;
+            if ((rc = stage_lights(c, lights, p.n_dir, nullptr, 0, true, s, sp, slot))) return rc;
+            p.dir_raw = sp.dir_raw;
+        }
+    }
+    if (flags & MIL_FLAG_STRICT) mil::strict::launch_accumulate(p, s);
+    else mil::fast::launch_accumulate(p, s);
+    return finish(c, slot, s);
+}
+
 int mil_count_pairs(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_push_constants *push,
                     const mil_point_light *pl, uint32_t n_point, unsigned long long *count, void *stream)
 {

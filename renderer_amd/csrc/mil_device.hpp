@@ -127,21 +127,16 @@ DEV void setup_pixel(Px &q, const ShadeParams &p, Pos pos, uint32_t u1, uint32_t
     q.V = normalize3(f3{ p.cam[0] - q.P.x, p.cam[1] - q.P.y, p.cam[2] - q.P.z }); // :59
 }
 
-// inc_brdf.glsl:49-63 with specular() :34-43, D_GGX :2-8, V_SmithGGXCorrelated :14-19, fresnel :25-32, diffuse :45-47
-DEV f3 brdf_light(const Px &q, f3 L, f3 lightColor)
+// specular(), inc_brdf.glsl:34-43, with D_GGX :2-8, V_SmithGGXCorrelated :14-19, fresnel :25-32
+DEV f3 brdf_specular(float alpha, f3 albedo, float metallic, float NdotV, float NdotL, float NdotH, float LdotH)
 {
-    f3 H = normalize3(f3{ L.x + q.V.x, L.y + q.V.y, L.z + q.V.z });
-    float NdotV = clampf(dot3(q.N, q.V), 0.0001f, 1.0f);
-    float NdotL = clampf(dot3(q.N, L), 0.0f, 1.0f);
-    float NdotH = clampf(dot3(q.N, H), 0.0f, 1.0f);
-    float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
-    float om = 1.0f - q.metallic;
-    f3 F0 = { 0.04f * om + q.albedo.x * q.metallic, 0.04f * om + q.albedo.y * q.metallic, 0.04f * om + q.albedo.z * q.metallic };
+    float om = 1.0f - metallic;
+    f3 F0 = { 0.04f * om + albedo.x * metallic, 0.04f * om + albedo.y * metallic, 0.04f * om + albedo.z * metallic };
     float oneMinusNoHSquared = 1.0f - NdotH * NdotH;
-    float a = NdotH * q.alpha;
-    float k = q.alpha / (oneMinusNoHSquared + a * a);
+    float a = NdotH * alpha;
+    float k = alpha / (oneMinusNoHSquared + a * a);
     float D = (k * k) * (1.0f / PI_LIT);
-    float a2 = q.alpha * q.alpha;
+    float a2 = alpha * alpha;
     float GGXV = NdotL * sqrtf((NdotV - a2 * NdotV) * NdotV + a2);
     float GGXL = NdotV * sqrtf((NdotL - a2 * NdotL) * NdotL + a2);
     float Vis = 0.5f / (GGXV + GGXL);
@@ -150,7 +145,18 @@ DEV f3 brdf_light(const Px &q, f3 L, f3 lightColor)
     float w = 1.0f - LdotH, w2 = w * w, w4 = w2 * w2, pw = w4 * w;
     f3 F = { F0.x + (f90 - F0.x) * pw, F0.y + (f90 - F0.y) * pw, F0.z + (f90 - F0.z) * pw };
     float DV = D * Vis;
-    f3 spec = { DV * F.x, DV * F.y, DV * F.z };
+    return f3{ DV * F.x, DV * F.y, DV * F.z };
+}
+// light(), inc_brdf.glsl:49-63, with diffuse :45-47
+DEV f3 brdf_light(const Px &q, f3 L, f3 lightColor)
+{
+    f3 H = normalize3(f3{ L.x + q.V.x, L.y + q.V.y, L.z + q.V.z });
+    float NdotV = clampf(dot3(q.N, q.V), 0.0001f, 1.0f);
+    float NdotL = clampf(dot3(q.N, L), 0.0f, 1.0f);
+    float NdotH = clampf(dot3(q.N, H), 0.0f, 1.0f);
+    float LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
+    float om = 1.0f - q.metallic;
+    f3 spec = brdf_specular(q.alpha, q.albedo, q.metallic, NdotV, NdotL, NdotH, LdotH);
     f3 diff = { q.albedo.x / PI_LIT, q.albedo.y / PI_LIT, q.albedo.z / PI_LIT };
     f3 color = { diff.x * om + (spec.x * om + (spec.x * q.albedo.x) * q.metallic),
                  diff.y * om + (spec.y * om + (spec.y * q.albedo.y) * q.metallic),
@@ -1591,6 +1597,87 @@ __global__ __launch_bounds__(256) void k_resolve(const ResolveParams p)
 }
 
 // ---------------------------------------------------------------------------------
+// K8 (next row f-2, second half): the fragment shader of the transparency accumulate draw,
+// renderer/shaders/fs_mcguire13_accumulation.glsl:100-126 (draw render/mod.rs:229-281), over a fragment list:
+// one fragment per lane, 52 B read + 20 B written per fragment, all 16-byte accesses of consecutive lanes
+// contiguous.  Unlike light(): no NdotL on the diffuse term, no intensity, no occlusion, roughness unclamped.
+// ---------------------------------------------------------------------------------
+DEV DirRec accum_dir_rec(const AccumParams &p, uint32_t l)
+{
+    DirRec d;
+    if (l < DIR_INLINE) {
+        const float *r = p.dir_inline[l];
+        d.a = v4f{ r[0], r[1], r[2], r[3] }; d.b = v4f{ r[4], r[5], r[6], r[7] };
+    } else {
+        d.a = ldu(p.dir_raw, 2 * l); d.b = ldu(p.dir_raw, 2 * l + 1);
+    }
+    return d;
+}
+__global__ __launch_bounds__(256) void k_accumulate(const AccumParams p)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.count) return;
+    const v4f pz = __builtin_nontemporal_load((const v4f *)p.pos_z + i), no = __builtin_nontemporal_load((const v4f *)p.nrm_op + i);
+    const v4f ar = __builtin_nontemporal_load((const v4f *)p.alb_rough + i);
+    const float metallic = __builtin_nontemporal_load(p.metallic + i), opacity = no.w;
+    const f3 albedo = { ar.x, ar.y, ar.z };
+    const float alpha = ar.w * ar.w;                                                  // :104
+    f3 lighting = { 0.0f, 0.0f, 0.0f };
+#if MIL_STRICT
+    const f3 N = normalize3(f3{ no.x, no.y, no.z });                                  // :106
+    const f3 V = normalize3(f3{ p.cam[0] - pz.x, p.cam[1] - pz.y, p.cam[2] - pz.z }); // :107
+    for (uint32_t l = 0; l < p.n_dir; l++) {                                          // :110-119
+        const DirRec d = accum_dir_rec(p, l);
+        const f3 L = { d.a.x, d.a.y, d.a.z };
+        const f3 H = normalize3(f3{ L.x + V.x, L.y + V.y, L.z + V.z });
+        const float NdotV = clampf(dot3(N, V), 0.0001f, 1.0f), NdotL = clampf(dot3(N, L), 0.0f, 1.0f);
+        const float NdotH = clampf(dot3(N, H), 0.0f, 1.0f), LdotH = clampf(dot3(L, H), 0.0f, 1.0f);
+        const f3 spec = brdf_specular(alpha, albedo, metallic, NdotV, NdotL, NdotH, LdotH);
+        lighting.x = lighting.x + (albedo.x / PI_LIT + (spec.x * d.b.x) * NdotL);
+        lighting.y = lighting.y + (albedo.y / PI_LIT + (spec.y * d.b.y) * NdotL);
+        lighting.z = lighting.z + (albedo.z / PI_LIT + (spec.z * d.b.z) * NdotL);
+    }
+    const float f = 1.0f - pz.w;                                                      // w10, :84-87
+    const float w = opacity * fmaxf(0.01f, ((3000.0f * f) * f) * f);
+    const v4f acc = { (lighting.x * opacity) * w, (lighting.y * opacity) * w, (lighting.z * opacity) * w, opacity * w };
+#else
+    // light-invariant terms hoisted as in setup_pixel_t; the n_dir diffuse terms are added once at the end
+    const f3 n = { no.x, no.y, no.z }, D = { p.cam[0] - pz.x, p.cam[1] - pz.y, p.cam[2] - pz.z };
+    const float rn = rsq_(dot3(n, n)), rv = rsq_(dot3(D, D));
+    const f3 N = { n.x * rn, n.y * rn, n.z * rn }, V = { D.x * rv, D.y * rv, D.z * rv };
+    const float a2 = alpha * alpha, am1 = a2 - 1.0f;
+    const float NdotV = med3_(dot3(N, V), 0.0001f, 1.0f);
+    const float sV = sqrt_(fma_(fma_(-a2, NdotV, NdotV), NdotV, a2));
+    const float om = 1.0f - metallic;
+    const f3 F0 = { fma_(albedo.x, metallic, 0.04f * om), fma_(albedo.y, metallic, 0.04f * om), fma_(albedo.z, metallic, 0.04f * om) };
+    const float f90 = sat((F0.x + F0.y + F0.z) * 16.5f);
+    const f3 dF = { f90 - F0.x, f90 - F0.y, f90 - F0.z };
+    for (uint32_t l = 0; l < p.n_dir; l++) {
+        const DirRec d = accum_dir_rec(p, l);
+        const f3 L = { d.a.x, d.a.y, d.a.z }, H = { L.x + V.x, L.y + V.y, L.z + V.z };
+        const float rh = rsq_(max_(dot3(H, H), 1e-30f));                              // L = -V: see eval_light
+        const float NdotL = sat(dot3(N, L)), NdotH = sat(dot3(N, H) * rh), LdotH = sat(dot3(L, H) * rh);
+        const float x2 = NdotH * NdotH;
+        const float k = alpha * rcp_(max_(fma_(x2, am1, 1.0f), a2));                   // see eval_tail
+        const float sL = sqrt_(fma_(fma_(-a2, NdotL, NdotL), NdotL, a2));
+        const float den = fma_(NdotL, sV, NdotV * sL);
+        const float t = ((k * k) * ((0.5f / PI_LIT) * rcp_(den))) * NdotL;            // D * Vis * NdotL
+        const float w1 = 1.0f - LdotH, w2 = w1 * w1, w5 = w2 * w2 * w1;
+        lighting.x = fma_(fma_(dF.x, w5, F0.x) * d.b.x, t, lighting.x);
+        lighting.y = fma_(fma_(dF.y, w5, F0.y) * d.b.y, t, lighting.y);
+        lighting.z = fma_(fma_(dF.z, w5, F0.z) * d.b.z, t, lighting.z);
+    }
+    const float nd = (float)p.n_dir * (1.0f / PI_LIT);
+    lighting = f3{ fma_(albedo.x, nd, lighting.x), fma_(albedo.y, nd, lighting.y), fma_(albedo.z, nd, lighting.z) };
+    const float f = 1.0f - pz.w;
+    const float aw = opacity * (opacity * max_(0.01f, 3000.0f * f * f * f));
+    const v4f acc = { lighting.x * aw, lighting.y * aw, lighting.z * aw, aw };
+#endif
+    __builtin_nontemporal_store(acc, (v4f *)p.accum + i);
+    __builtin_nontemporal_store(opacity, p.reveal + i);
+}
+
+// ---------------------------------------------------------------------------------
 // launchers (host)
 // ---------------------------------------------------------------------------------
 void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
@@ -1679,6 +1766,10 @@ void launch_resolve(const ResolveParams &p, hipStream_t s)
 {
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
     hipLaunchKernelGGL(k_resolve, grid, block, 0, s, p);
+}
+void launch_accumulate(const AccumParams &p, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_accumulate, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
 }
 #if !MIL_STRICT
 void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)

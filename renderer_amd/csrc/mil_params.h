@@ -85,6 +85,17 @@ struct ResolveParams {        // transparency resolve: accum RGBA16F + reveal R1
     uint32_t width, height, accum_pitch, reveal_pitch, hdr_pitch;
 };
 
+struct AccumParams {          // transparency accumulate over a fragment list (fs_mcguire13_accumulation.glsl:90-127)
+    const float4 *pos_z, *nrm_op, *alb_rough;   // see mil_transparent_fragments
+    const float *metallic;
+    float4 *accum;
+    float *reveal;
+    uint32_t count, n_dir;
+    float cam[3];
+    float dir_inline[MIL_DIR_INLINE][8];        // RAW records {direction, intensity} {color, pad} in both modes
+    const float4 *dir_raw;                      // (the shader does not use the intensity)
+};
+
 // implemented once per numeric mode
 namespace fast {
 void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
@@ -94,6 +105,7 @@ void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStre
 void launch_fxaa(const FxaaParams &p, hipStream_t s);
 void launch_sky(const SkyParams &p, hipStream_t s);
 void launch_resolve(const ResolveParams &p, hipStream_t s);
+void launch_accumulate(const AccumParams &p, hipStream_t s);
 }
 namespace strict {
 void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
@@ -102,6 +114,7 @@ void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 void launch_fxaa(const FxaaParams &p, hipStream_t s);
 void launch_sky(const SkyParams &p, hipStream_t s);
 void launch_resolve(const ResolveParams &p, hipStream_t s);
+void launch_accumulate(const AccumParams &p, hipStream_t s);
 }
 
 } // namespace mil

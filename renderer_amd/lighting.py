@@ -24,7 +24,8 @@ TILE = 16
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
-           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame']
+           'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame',
+           'mil_transparency_accumulate']
 
 
 class MilError(RuntimeError):
@@ -51,6 +52,11 @@ class Extras(ctypes.Structure):            # mil_extras
 class FramePasses(ctypes.Structure):      # mil_frame_passes
     _fields_ = [('sky', ctypes.c_void_p), ('accum', ctypes.c_void_p), ('reveal', ctypes.c_void_p),
                 ('accum_pitch_px', ctypes.c_uint32), ('reveal_pitch_px', ctypes.c_uint32)]
+
+
+class TransparentFragments(ctypes.Structure):   # mil_transparent_fragments
+    _fields_ = [('position_depth', ctypes.c_void_p), ('normal_opacity', ctypes.c_void_p),
+                ('albedo_roughness', ctypes.c_void_p), ('metallic', ctypes.c_void_p), ('count', ctypes.c_uint32)]
 
 
 _lib = None
@@ -87,6 +93,7 @@ def load_library(path=LIB_PATH):
         lib.mil_fxaa.argtypes = [vp, vp, u32, u32, u32, u32, u32, vp, u32, u32, vp]
         lib.mil_sky_hosek.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, u32, vp]
         lib.mil_transparency_resolve.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp, u32, u32, vp]
+        lib.mil_transparency_accumulate.argtypes = [vp, ctypes.POINTER(TransparentFragments), vp, vp, vp, vp, vp, u32, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
         _lib = lib
     return _lib
@@ -200,6 +207,28 @@ class LightingPass:
                                                       reveal.stride(0), w, h, hdr.data_ptr(), hdr.stride(0) // 4,
                                                       FLAG_STRICT if strict else 0, self._stream(stream)))
         return hdr
+
+    def transparency_accumulate(self, fragments, frame, lights, accum=None, reveal=None, strict=False, stream=None):
+        """The fragment shader of the accumulate draw (render/mod.rs:229-281, fs_mcguire13_accumulation.glsl:100-126) over a
+        fragment list: fragments = dict of float32 CUDA tensors position_depth / normal_opacity / albedo_roughness (n, 4),
+        metallic (n,).  Returns accum (n, 4), reveal (n,): the values the blend stage consumes."""
+        t = self.torch
+        planes = [fragments[k] for k in ('position_depth', 'normal_opacity', 'albedo_roughness', 'metallic')]
+        n = planes[3].shape[0]
+        for a, shape in zip(planes, ((n, 4), (n, 4), (n, 4), (n,))):
+            assert a.is_cuda and a.dtype == t.float32 and a.is_contiguous() and tuple(a.shape) == shape
+        lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 8)
+        frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+        push = ubo.push_constants(1, 1, lights.shape[0])
+        if accum is None:
+            accum = t.empty((n, 4), dtype=t.float32, device=self.device)
+        if reveal is None:
+            reveal = t.empty((n,), dtype=t.float32, device=self.device)
+        fr = TransparentFragments(*(a.data_ptr() for a in planes), n)
+        self._check(self.lib.mil_transparency_accumulate(self.ctx, ctypes.byref(fr), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
+                                                         accum.data_ptr(), reveal.data_ptr(), FLAG_STRICT if strict else 0,
+                                                         self._stream(stream)))
+        return accum, reveal
 
     def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,
                  flags=0, out=None, stream=None):

@@ -228,3 +228,20 @@ def transparency_layer(w, h, device):
     acc[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = torch.tensor([0.5, 0.4, 0.3, 0.8], dtype=torch.float16, device=device)
     rev[h // 3: 2 * h // 3, w // 4: 3 * w // 4] = 0.4
     return acc, rev
+
+
+def transparent_fragments(n, seed=0):
+    """n fragments of a transparency accumulate draw (mil_transparent_fragments; numpy float32): positions in a 8 x 3 x 8
+    box around the origin, unnormalised interpolated normals, gl_FragCoord.z in (0.2, 0.999), roughness >= 0.02 (the
+    accumulate shader does not clamp it: 0 is NaN in the reference too)."""
+    rng = np.random.RandomState(seed)
+    f = np.float32
+    pos = (rng.rand(n, 3) * np.array([8.0, 3.0, 8.0]) - np.array([4.0, 0.0, 4.0])).astype(f)
+    z = (0.2 + 0.799 * rng.rand(n, 1)).astype(f)
+    nrm = rng.randn(n, 3)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True) * (0.5 + rng.rand(n, 1))).astype(f)
+    opacity = (0.05 + 0.95 * rng.rand(n, 1)).astype(f)
+    albedo = rng.rand(n, 3).astype(f)
+    rough = (0.02 + 0.98 * rng.rand(n, 1)).astype(f)
+    return {'position_depth': np.concatenate([pos, z], 1), 'normal_opacity': np.concatenate([nrm, opacity], 1),
+            'albedo_roughness': np.concatenate([albedo, rough], 1), 'metallic': rng.rand(n).astype(f)}

@@ -8,6 +8,7 @@ writes tests/golden/glsl_reference.npz: outputs of
     fs_mcguire13_resolve.glsl (+ the blend of mcguire13/mod.rs:108-120, applied here in float32)
     sky_hosek_frag.glsl                                            on the sky texels of the sweep fixture
     fs_fxaa.glsl                                                   on the ldr frame of fxaa_101x70.npz
+    fs_mcguire13_accumulation.glsl (+ inc_brdf.glsl)               on 600 synthetic fragments (material factors x texels)
 What stays outside the reference's source - texel format decode/encode, built-in precision, blending - is done by this
 script the way the oracles do it (see oracle/glsl_exec.py) and remains unpinned."""
 import os
@@ -121,6 +122,35 @@ def main():
     col = sh.run(w * h, uniforms={'push_constants': dict(resolution=np.array([w, h], F32))}, frag_coord=frag_coord(w, h),
                  samplers={'tex': tex})['f_color']
     out['fxaa_color'] = col.reshape(h, w, 4)
+    # ---- transparency accumulate: per-fragment varyings, texels and material factors in; the planes of
+    # mil_transparent_fragments are the FP32 products the shader forms on its first lines (:91-96)
+    P = 600
+    fr = synth.transparent_fragments(P, seed=13)
+    rng = np.random.RandomState(14)
+    mat = dict(albedo_color=np.array([0.9, 0.8, 0.7], F32), alpha_cutoff=0.5, roughness=F32(0.85), metallic=F32(0.6), opacity=F32(0.75), ior=1.0)
+    texel = {k: rng.rand(P, 4).astype(F32) for k in ('albedo_map', 'roughness_map', 'metallic_map', 'opacity_map')}
+    texel['roughness_map'][:, 0] = F32(0.03) + F32(0.97) * texel['roughness_map'][:, 0]
+    other = rng.rand(P, 4).astype(F32)
+    samplers = {k: (lambda uv, v=v: v) for k, v in texel.items()}
+    samplers.update({k: (lambda uv: other) for k in ('normal_map', 'displacement_map', 'occlusion_map')})
+    dl = np.concatenate([sweep['dir_lights'], np.array([[-0.3, 0.5, 0.81, 3.0, 0.2, 0.9, 0.5, 0.0]], F32)])
+    cam = np.asarray(sweep['frame'], F32).reshape(-1)[64:67]
+    sh = glsl_exec.Shader(SHADERS + 'fs_mcguire13_accumulation.glsl')
+    fc = np.concatenate([rng.rand(P, 2) * 90, fr['position_depth'][:, 3:4], np.ones((P, 1))], 1).astype(F32)
+    res = sh.run(P, uniforms={'frame_matrix_data': frame_uniforms(sweep['frame']),
+                              'lights_ubo': dict(lights=[dict(direction=l[0:3], intensity=l[3], color=l[4:7]) for l in dl]),
+                              'push_constants': dict(resolution=np.array([96, 54], F32), light_count=len(dl)),
+                              'TheBlock': dict(material_data=mat)},
+                 frag_coord=fc, samplers=samplers,
+                 varyings={'in_uv': rng.rand(P, 2), 'in_tbn': np.zeros((P, 9)), 'in_wsPosition': fr['position_depth'][:, :3],
+                           'in_normal': fr['normal_opacity'][:, :3]})
+    out['accumulate_position_depth'] = fr['position_depth']
+    out['accumulate_normal_opacity'] = np.concatenate([fr['normal_opacity'][:, :3], (mat['opacity'] * texel['opacity_map'][:, :1]).astype(F32)], 1)
+    out['accumulate_albedo_roughness'] = np.concatenate([(mat['albedo_color'] * texel['albedo_map'][:, :3]).astype(F32),
+                                                         (mat['roughness'] * texel['roughness_map'][:, :1]).astype(F32)], 1)
+    out['accumulate_metallic'] = (mat['metallic'] * texel['metallic_map'][:, 0]).astype(F32)
+    out['accumulate_camera'], out['accumulate_dir_lights'] = cam, dl
+    out['accumulate_accum'], out['accumulate_reveal'] = res['accum'], res['reveal'][:, 0]
     np.savez_compressed(os.path.join(OUT, 'glsl_reference.npz'), **out)
     print('wrote', os.path.join(OUT, 'glsl_reference.npz'), {k: v.shape for k, v in out.items()})
 

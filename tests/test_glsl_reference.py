@@ -77,6 +77,21 @@ def test_fxaa_shader(ref, coracle):
     assert np.all(ref['fxaa_color'][..., 3] == 1)
 
 
+def accumulate_inputs(ref):
+    return [ref['accumulate_' + k] for k in ('position_depth', 'normal_opacity', 'albedo_roughness', 'metallic', 'camera', 'dir_lights')]
+
+
+def test_accumulate_shader(ref, coracle):
+    acc, rev = coracle.transparency_accumulate(*accumulate_inputs(ref))
+    assert bits_equal(ref['accumulate_accum'], acc) and bits_equal(ref['accumulate_reveal'], rev)
+    assert np.isfinite(acc).all() and np.all(acc[:, 3] > 0) and np.array_equal(rev, ref['accumulate_normal_opacity'][:, 3])
+    a64, r64 = mo.transparency_accumulate(*accumulate_inputs(ref))
+    assert np.all(np.abs(a64 - acc) <= 1e-5 + 2e-4 * np.abs(a64)) and np.array_equal(r64, rev)
+    # no lights: accum = (0, 0, 0, opacity) * w10, the weight alone
+    a0, _ = coracle.transparency_accumulate(*accumulate_inputs(ref)[:5], np.zeros((0, 8), np.float32))
+    assert np.all(a0[:, :3] == 0) and bits_equal(a0[:, 3], acc[:, 3])
+
+
 @pytest.mark.skipif(not os.path.isdir(SHADERS), reason='the reference tree exists only in the development container')
 def test_fixture_regenerates_from_the_reference_source(ref, tmp_path, monkeypatch):
     """Runs the interpreter on the reference's shader files again: the committed fixture is what they produce."""

@@ -497,6 +497,48 @@ def test_transparency_resolve(lp, coracle):
         assert np.array_equal(fast[rev == 1], hdr0[rev == 1])               # nothing transparent there: hdr untouched
 
 
+def frags_to_device(fr):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in fr.items()}
+
+
+def test_transparency_accumulate(lp, coracle):
+    """mil_transparency_accumulate (fs_mcguire13_accumulation.glsl over a fragment list): strict bit for bit against the C
+    oracle, fast within 1e-3 + 1e-4 |x| (+ the D_GGX conditioning term) of the float64 restatement; ragged sizes, 0 / 1 / 7 / 100 directional lights
+    (beyond the 4 inline records the raw array comes from a staged slot), the empty list, the light-count limit."""
+    cam = synth.sweep_camera(320, 180)
+    frame = cam.frame_matrix_data()
+    rng = np.random.RandomState(3)
+    for n, n_dir in [(1, 2), (63, 1), (257, 0), (5000, 2), (40001, 7), (3000, 100)]:
+        fr = synth.transparent_fragments(n, seed=n)
+        dl = np.concatenate([ubo.default_directional_lights(),
+                             ubo.directional_lights([(d, 0.5 + i, rng.rand(3)) for i, d in enumerate(rng.randn(max(n_dir - 2, 0), 3))])])[:n_dir]
+        dev = frags_to_device(fr)
+        args = [fr[k] for k in ('position_depth', 'normal_opacity', 'albedo_roughness', 'metallic')] + [frame[64:67], dl]
+        ca, cr = coracle.transparency_accumulate(*args)
+        sa, sr = lp.transparency_accumulate(dev, frame, dl, strict=True)
+        assert_bits_equal(sa.cpu().numpy(), ca, f'accumulate strict n={n} lights={n_dir}')
+        assert np.array_equal(sr.cpu().numpy(), cr)
+        fa, frv = lp.transparency_accumulate(dev, frame, dl)
+        ra, rr, cond = mo.transparency_accumulate(*args, want_cond=True)
+        assert np.isfinite(ra).all()
+        tol = 1e-3 + 1e-4 * np.abs(ra) + 8 * 2.0 ** -24 * cond          # as shade_and_compare: D_GGX ill-conditioned at mirror alignment
+        assert np.all(np.abs(fa.cpu().numpy() - ra) <= tol), (n, n_dir, float((np.abs(fa.cpu().numpy() - ra) / tol).max()))
+        assert np.all(np.abs(ca - ra) <= tol)
+        assert np.array_equal(frv.cpu().numpy(), fr['normal_opacity'][:, 3])
+    # the lighting call of the frame and the accumulate call share the staged light slot (same lights UBO in the reference)
+    gb, frame2, dl2, pl, _ = make_scene('sweep', 96, 64, n_point=16)
+    hdr_a = lp.light_ex(gb, frame2, dl, pl, AMB, None)
+    fa2, _ = lp.transparency_accumulate(dev, frame, dl)
+    hdr_b = lp.light_ex(gb, frame2, dl, pl, AMB, None)
+    assert torch.equal(fa2, fa) and torch.equal(hdr_a, hdr_b)
+    # empty list: nothing to do; too many lights: the reference panics (render/mod.rs:197-199), this returns the status
+    empty = {k: v[:0].contiguous() for k, v in dev.items()}
+    a0, r0 = lp.transparency_accumulate(empty, frame, dl)
+    assert a0.shape == (0, 4) and r0.shape == (0,)
+    with pytest.raises(lighting.MilError, match='-2'):
+        lp.transparency_accumulate(dev, frame, np.zeros((101, 8), np.float32))
+
+
 def test_shade_frame_equals_subpass_chain(lp):
     """mil_shade_frame (one launch) == mil_light_ex(HDR) -> mil_sky_hosek -> mil_transparency_resolve -> mil_tonemap,
     bit for bit in both numeric modes, on the streaming (no point lights) and the tiled kernel, whole frame and strip."""
@@ -736,6 +778,12 @@ def test_strict_kernels_vs_executed_reference_shaders(lp):
     assert same(lp.transparency_resolve(ta, tr, hdr.clone(), strict=True).cpu().numpy(), ref['resolve_hdr'])
     sky = lp.sky_hosek(gb, g['frame'], ref['sky_params'], hdr.clone(), strict=True).cpu().numpy()
     np.testing.assert_allclose(sky, ref['sky_hdr'], rtol=3e-7, atol=0)
+    # transparency accumulate: the fragment shader's two outputs
+    fr = frags_to_device({k: ref['accumulate_' + k] for k in ('position_depth', 'normal_opacity', 'albedo_roughness', 'metallic')})
+    frame_a = np.zeros(68, np.float32)
+    frame_a[64:67] = ref['accumulate_camera']
+    acc, rev = lp.transparency_accumulate(fr, frame_a, ref['accumulate_dir_lights'], strict=True)
+    assert same(acc.cpu().numpy(), ref['accumulate_accum']) and same(rev.cpu().numpy(), ref['accumulate_reveal'])
     # FXAA: the shader's float colour through the swapchain's sRGB8 encode
     f = np.load(os.path.join(GOLDEN, 'fxaa_101x70.npz'))
     enc = mo.encode_b8g8r8a8_srgb(ref['fxaa_color'][..., :3].astype(np.float64))
