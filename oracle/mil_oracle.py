@@ -236,6 +236,11 @@ def shade(normal_u32, albedo_occ_u32, rough_metal_u32, depth_f32, frame_ubo, dir
                 r, cond, sp = r
                 cond_bound += np.where(on[..., None], np.abs(sp) * (cond * float(pl[i, 7]) * att * occlusion)[..., None], 0.0)
             c = r * float(pl[i, 7]) * att[..., None] * occlusion[..., None]
+            if want_cond:
+                # 1/(d^2 + 1e-4) next to a light: d(att)/att = 2 d dP / (d^2 + 1e-4), and the position reconstructed from an
+                # FP32 depth carries an absolute error of a few ulps of |P| + |camera| (a hot spot centimetres from a light)
+                scale = np.sqrt(_dot(P, P)) + np.sqrt(np.sum(fr['camera_position'] ** 2))
+                cond_bound += np.where(on[..., None], np.abs(c) * (2.0 * np.sqrt(d2) * scale / (d2 + 1e-4))[..., None], 0.0)
             result += np.where(on[..., None], c, 0.0)
     if ambient is not None:                                  # EXTENSION E4
         amb = np.asarray(ambient, dtype=np.float32).astype(np.float64)
