@@ -7,7 +7,8 @@ Each iteration draws a frame size, strip, pitch, light counts, shadow size, flag
   * mil_shade_frame(fmt)                     == mil_light_ex + mil_sky_hosek + mil_transparency_resolve + mil_tonemap, bit for bit
   * mil_fxaa on a strip                      == the rows of the whole-frame call
   * mil_transparency_accumulate strict       == the C oracle, bit for bit
-Prints one line per failure with the seed that reproduces it; exit status 1 if any."""
+FUZZ_BIG=1: frames up to 1000 x 500 with 600 - 4000 point lights and shadow maps up to 2048^2 (seconds per iteration: the C
+oracle is brute force).  Prints one line per failure with the seed that reproduces it; exit status 1 if any."""
 import os
 import sys
 
@@ -32,13 +33,14 @@ def bits_eq(a, b):
 def one(lp, seed):
     rng = np.random.RandomState(seed)
     fails = []
-    w, full_h = int(rng.randint(1, 300)), int(rng.randint(1, 200))
+    big = bool(os.environ.get('FUZZ_BIG'))      # larger frames and light counts: tile lists beyond one LDS round, big shadow maps
+    w, full_h = (int(rng.randint(300, 1000)), int(rng.randint(100, 500))) if big else (int(rng.randint(1, 300)), int(rng.randint(1, 200)))
     y0 = int(rng.randint(0, full_h)) if rng.rand() < 0.4 else 0
     h = int(rng.randint(1, full_h - y0 + 1)) if y0 or rng.rand() < 0.3 else full_h
     kind = 'noise' if rng.rand() < 0.4 else 'sweep'
     n_dir = int(rng.choice([0, 1, 2, 2, 2, 5, 9]))
-    n_point = int(rng.choice([0, 0, 1, 7, 40, 130, 300]))
-    shadow = int(rng.choice([0, 0, 33, 64, 256]))
+    n_point = int(rng.choice([600, 1500, 4000])) if big else int(rng.choice([0, 0, 1, 7, 40, 130, 300]))
+    shadow = int(rng.choice([0, 512, 2048])) if big else int(rng.choice([0, 0, 33, 64, 256]))
     amb = (0.03, 0.02, 0.04) if rng.rand() < 0.6 else None
     pad_l, pad_r = (int(rng.randint(0, 9)), int(rng.randint(0, 9))) if rng.rand() < 0.4 else (0, 0)
     cam = synth.sweep_camera(w, full_h)
@@ -132,7 +134,7 @@ def main():
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     coracle.build()
-    lp = lighting.LightingPass(0, max_point_lights=512)
+    lp = lighting.LightingPass(0, max_point_lights=4096)
     total = []
     for i in range(iters):
         total += one(lp, seed0 + i)
