@@ -5,6 +5,7 @@ Each iteration draws a frame size, strip, pitch, light counts, shadow size, flag
   * fast                                     within the documented tolerance of the float64 restatement (small frames only;
                                                with a shadow map a PCF tap on the bias may flip: <= 1e-3 of the pixels or one pixel)
   * mil_shade_frame(fmt)                     == mil_light_ex + mil_sky_hosek + mil_transparency_resolve + mil_tonemap, bit for bit
+  * strict sky / resolve / tonemap chain      == the C oracle's chain (sky: to the last ulp of exp / pow / acos)
   * mil_fxaa on a strip                      == the rows of the whole-frame call
   * mil_transparency_accumulate strict       == the C oracle, bit for bit
 FUZZ_BIG=1: frames up to 1000 x 500 with 600 - 4000 point lights and shadow maps up to 2048^2 (seconds per iteration: the C
@@ -105,6 +106,15 @@ def one(lp, seed):
                               reveal=tr if use_acc else None, fmt=fmt, flags=flags)
         if not torch.equal(onec.view(torch.int32), chain.view(torch.int32)):
             fails.append(f'shade_frame != chain (fmt {fmt}, strict {st}, sky {use_sky}, resolve {use_acc}): ' + cfg)
+        if st:      # the strict chain against the C oracle's chain: sky to the last ulp of exp / pow / acos, the rest bit for bit
+            o = ref.copy()
+            if use_sky: o = coracle.sky_hosek(planes[3], frame, prm, o, y_offset=y0, full_height=full_h)
+            if use_acc: o = coracle.transparency_resolve(acc, rev, o)
+            g = hdr.cpu().numpy()
+            if not (bits_eq(g, o) if not use_sky else (np.allclose(g, o, rtol=1e-6, atol=0, equal_nan=True))):
+                fails.append(f'strict chain != C oracle chain (sky {use_sky}, resolve {use_acc}): ' + cfg)
+            if fmt != lighting.OUT_HDR and not np.array_equal(chain.cpu().numpy().view(np.uint32), coracle.tonemap(g, fmt)):
+                fails.append(f'strict tonemap fmt {fmt} != C oracle: ' + cfg)
 
     # FXAA strip == rows of the whole frame
     if h == full_h:
