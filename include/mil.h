@@ -14,7 +14,7 @@
  * uniform struct / light array pointer is HOST memory, copied during the call
  * (mirrors the reference's per-frame CpuBufferPool ring, render/pools.rs:42-57).
  * Calls enqueue work on `stream` (a hipStream_t, 0 = default stream) and return;
- * no call allocates after mil_create.  One context = one thread at a time.
+ * no per-frame call allocates after mil_create (the external-memory set-up calls below do).  One context = one thread at a time.
  * All functions return 0 on success or a negative mil_status; nothing aborts.
  */
 #ifndef MIL_H
@@ -232,6 +232,20 @@ int mil_shade_frame(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     const mil_directional_light *lights, const mil_push_constants *push,
                     const mil_extras *extras, const mil_frame_passes *passes, void *out, uint32_t out_pitch_px,
                     mil_out_format fmt, uint32_t flags, void *stream);
+
+/* NEXT ROW, the HIP half of the Vulkan <-> HIP hand-over.  The reference's attachments are Vulkan
+ * images (render/pbr/mod.rs:76-95,150-160); to be read or written by this library their memory must be one allocation
+ * visible to both APIs.  Either direction works through a POSIX fd (on amdgpu a dma-buf):
+ *   mil_import_external_memory   Vulkan allocates with VkExportMemoryAllocateInfo (OPAQUE_FD), vkGetMemoryFdKHR gives fd
+ *   mil_alloc_exportable_memory  this library allocates and returns an fd for VkImportMemoryFdInfoKHR
+ * dev_ptr is what mil_gbuffer / hdr / out take (linear, buffer-backed images).  The fd stays the
+ * caller's: close it once the other side has imported it.  These are set-up calls (they allocate); queue ordering is the
+ * caller's (an exported semaphore, or vkQueueWaitIdle / mil_sync). */
+typedef struct mil_external_memory mil_external_memory;
+int mil_import_external_memory(mil_ctx *ctx, int fd, uint64_t size, mil_external_memory **mem, void **dev_ptr);
+int mil_alloc_exportable_memory(mil_ctx *ctx, uint64_t size, mil_external_memory **mem, void **dev_ptr, int *fd,
+                                uint64_t *allocated_size /* size rounded up to the allocation granularity; may be NULL */);
+int mil_release_external_memory(mil_ctx *ctx, mil_external_memory *mem);
 
 /* Diagnostics for the roofline accounting: number of (pixel, point light) pairs
  * with d^2 < r^2 and occlusion > 0, by brute force (independent of the culling).

@@ -1,7 +1,8 @@
 // Host runtime of libmil.so: the C ABI declared in include/mil.h.
 // Owns a small ring of staged light buffers (the counterpart of the reference's
 // per-frame CpuBufferPool ring, render/pools.rs:42-57); everything else belongs to
-// the caller.  No allocation happens after mil_create.
+// the caller.  The per-frame calls allocate nothing after mil_create; the external-memory
+// set-up calls are the only other allocators.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <new>
@@ -34,6 +35,16 @@ struct Slot {
 };
 
 } // namespace
+
+struct mil_external_memory {
+    bool imported = false;
+    size_t size = 0;
+    hipExternalMemory_t ext = nullptr;             // imported: the external-memory object and its mapped buffer
+    void *mapped = nullptr;
+    hipMemGenericAllocationHandle_t handle = {};   // exportable: physical allocation + the virtual range it is mapped at
+    void *va = nullptr;
+    bool have_handle = false, is_mapped = false;
+};
 
 struct mil_ctx {
     int device = 0;
@@ -621,6 +632,87 @@ int mil_transparency_accumulate(mil_ctx *c, const mil_transparent_fragments *fr,
     if (flags & MIL_FLAG_STRICT) mil::strict::launch_accumulate(p, s);
     else mil::fast::launch_accumulate(p, s);
     return finish(c, slot, s);
+}
+
+int mil_import_external_memory(mil_ctx *c, int fd, uint64_t size, mil_external_memory **mem, void **dev_ptr)
+{
+    if (!c || fd < 0 || size == 0 || !mem || !dev_ptr) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    hipExternalMemoryHandleDesc d;
+    memset(&d, 0, sizeof(d));
+    d.type = hipExternalMemoryHandleTypeOpaqueFd;
+    d.handle.fd = fd;
+    d.size = size;
+    mil_external_memory *m = new (std::nothrow) mil_external_memory();
+    if (!m) return MIL_ERR_HIP;
+    m->imported = true; m->size = (size_t)size;
+    hipError_t e = hipImportExternalMemory(&m->ext, &d);
+    if (e == hipSuccess) {
+        hipExternalMemoryBufferDesc b;
+        memset(&b, 0, sizeof(b));
+        b.size = size;
+        e = hipExternalMemoryGetMappedBuffer(&m->mapped, m->ext, &b);
+        if (e != hipSuccess) (void)hipDestroyExternalMemory(m->ext);
+    }
+    if (e != hipSuccess) { delete m; return hip_fail(c, e); }
+    *mem = m; *dev_ptr = m->mapped;
+    return MIL_OK;
+}
+
+int mil_alloc_exportable_memory(mil_ctx *c, uint64_t size, mil_external_memory **mem, void **dev_ptr, int *fd, uint64_t *allocated_size)
+{
+    if (!c || size == 0 || !mem || !dev_ptr || !fd) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    prop.requestedHandleType = hipMemHandleTypePosixFileDescriptor;
+    size_t gran = 0;
+    HIP_TRY(c, hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
+    if (gran == 0) gran = 4096;
+    mil_external_memory *m = new (std::nothrow) mil_external_memory();
+    if (!m) return MIL_ERR_HIP;
+    m->size = ((size_t)size + gran - 1) / gran * gran;
+    hipError_t e = hipMemCreate(&m->handle, m->size, &prop, 0);
+    m->have_handle = e == hipSuccess;
+    if (e == hipSuccess) e = hipMemAddressReserve(&m->va, m->size, 0, nullptr, 0);
+    if (e == hipSuccess) { e = hipMemMap(m->va, m->size, 0, m->handle, 0); m->is_mapped = e == hipSuccess; }
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc;
+        memset(&acc, 0, sizeof(acc));
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(m->va, m->size, &acc, 1);
+    }
+    int out_fd = -1;
+    if (e == hipSuccess) e = hipMemExportToShareableHandle(&out_fd, m->handle, hipMemHandleTypePosixFileDescriptor, 0);
+    if (e != hipSuccess) { (void)mil_release_external_memory(c, m); return hip_fail(c, e); }
+    *mem = m; *dev_ptr = m->va; *fd = out_fd;
+    if (allocated_size) *allocated_size = m->size;
+    return MIL_OK;
+}
+
+int mil_release_external_memory(mil_ctx *c, mil_external_memory *m)
+{
+    if (!c || !m) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    hipError_t first = hipSuccess;
+    auto keep = [&](hipError_t e) { if (first == hipSuccess) first = e; };
+    if (m->imported) {
+        if (m->mapped) keep(hipFree(m->mapped));
+        if (m->ext) keep(hipDestroyExternalMemory(m->ext));
+    } else {
+        if (m->is_mapped) keep(hipMemUnmap(m->va, m->size));
+        if (m->va) keep(hipMemAddressFree(m->va, m->size));
+        if (m->have_handle) keep(hipMemRelease(m->handle));
+    }
+    delete m;
+    return first == hipSuccess ? MIL_OK : hip_fail(c, first);
 }
 
 int mil_count_pairs(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_push_constants *push,

@@ -25,7 +25,8 @@ TILE = 16
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
            'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame',
-           'mil_transparency_accumulate']
+           'mil_transparency_accumulate', 'mil_import_external_memory', 'mil_alloc_exportable_memory',
+           'mil_release_external_memory']
 
 
 class MilError(RuntimeError):
@@ -94,6 +95,10 @@ def load_library(path=LIB_PATH):
         lib.mil_sky_hosek.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, u32, u32, vp]
         lib.mil_transparency_resolve.argtypes = [vp, vp, u32, vp, u32, u32, u32, vp, u32, u32, vp]
         lib.mil_transparency_accumulate.argtypes = [vp, ctypes.POINTER(TransparentFragments), vp, vp, vp, vp, vp, u32, vp]
+        lib.mil_import_external_memory.argtypes = [vp, ctypes.c_int, ctypes.c_uint64, ctypes.POINTER(vp), ctypes.POINTER(vp)]
+        lib.mil_alloc_exportable_memory.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp), ctypes.POINTER(vp),
+                                                    ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
+        lib.mil_release_external_memory.argtypes = [vp, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
         _lib = lib
     return _lib
@@ -229,6 +234,31 @@ class LightingPass:
                                                          accum.data_ptr(), reveal.data_ptr(), FLAG_STRICT if strict else 0,
                                                          self._stream(stream)))
         return accum, reveal
+
+    # ---- SURVEY.md 8 f-3, HIP half: device memory shared with another API through a POSIX fd (dma-buf)
+    def alloc_exportable_memory(self, size):
+        """-> (mem handle, device pointer, fd, allocated size); the fd is the caller's to hand over and close."""
+        mem, ptr, fd, real = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int(-1), ctypes.c_uint64()
+        self._check(self.lib.mil_alloc_exportable_memory(self.ctx, size, ctypes.byref(mem), ctypes.byref(ptr), ctypes.byref(fd), ctypes.byref(real)))
+        return mem, ptr.value, fd.value, real.value
+
+    def import_external_memory(self, fd, size):
+        """-> (mem handle, device pointer) of an allocation another API exported as fd (vkGetMemoryFdKHR)."""
+        mem, ptr = ctypes.c_void_p(), ctypes.c_void_p()
+        self._check(self.lib.mil_import_external_memory(self.ctx, fd, size, ctypes.byref(mem), ctypes.byref(ptr)))
+        return mem, ptr.value
+
+    def release_external_memory(self, mem):
+        self._check(self.lib.mil_release_external_memory(self.ctx, mem))
+
+    def tensor_at(self, ptr, shape, dtype):
+        """A torch tensor over raw device memory (no copy, no ownership): how tests and bench address imported memory."""
+        t = self.torch
+        typestr = {t.float32: '<f4', t.int32: '<i4', t.float16: '<f2', t.uint8: '|u1'}[dtype]
+
+        class _Raw:
+            __cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2)
+        return t.as_tensor(_Raw(), device=self.device)
 
     def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,
                  flags=0, out=None, stream=None):

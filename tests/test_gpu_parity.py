@@ -539,6 +539,54 @@ def test_transparency_accumulate(lp, coracle):
         lp.transparency_accumulate(dev, frame, np.zeros((101, 8), np.float32))
 
 
+def test_external_memory_hand_over(lp):
+    """SURVEY.md 8 f-3, HIP half: every image of a frame lives in ONE allocation that is exported as a POSIX fd (what
+    VK_KHR_external_memory_fd hands out on amdgpu is such a dma-buf) and imported with mil_import_external_memory; the
+    passes read the G-buffer and write hdr / ldr / swapchain through the imported mapping.  Results equal the ones on
+    ordinary allocations bit for bit, and are visible through the exporting side's mapping (same memory)."""
+    w, h = 200, 120
+    gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=24, shadow=128)
+    px = w * h
+    need = px * (4 * 4 + 16 + 4 + 4)
+    mem_a, ptr_a, fd, size = lp.alloc_exportable_memory(need)
+    assert size >= need and fd >= 0
+    mem_b, ptr_b = lp.import_external_memory(fd, size)
+    os.close(fd)                                                # both sides hold their own reference now
+    assert ptr_b != ptr_a
+    try:
+        off = 0
+        def carve(base, n_bytes):
+            nonlocal off
+            p = base + off
+            off += n_bytes
+            return p
+        gbx = dict(gb)
+        for k in ('normal', 'albedo_occ', 'rough_metal', 'depth'):
+            t = lp.tensor_at(carve(ptr_b, px * 4), (h, w), gb[k].dtype)
+            t.copy_(gb[k])
+            gbx[k] = t
+        hdr_off = off
+        hdr_x = lp.tensor_at(carve(ptr_b, px * 16), (h, w, 4), torch.float32)
+        ldr_x = lp.tensor_at(carve(ptr_b, px * 4), (h, w), torch.int32)
+        out_x = lp.tensor_at(carve(ptr_b, px * 4), (h, w), torch.int32)
+        for flags in (0, lighting.FLAG_STRICT):
+            st = bool(flags)
+            ref_hdr = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=flags)
+            ref_out = lp.fxaa(lp.tonemap(ref_hdr, lighting.OUT_LDR, strict=st), strict=st)
+            lp.light_ex(gbx, frame, dl, pl, AMB, sh, flags=flags, out=hdr_x)
+            lp.tonemap(hdr_x, lighting.OUT_LDR, out=ldr_x, strict=st)
+            lp.fxaa(ldr_x, out=out_x, strict=st)
+            assert torch.equal(hdr_x.view(torch.int32), ref_hdr.view(torch.int32)) and torch.equal(out_x, ref_out)
+            seen_by_exporter = lp.tensor_at(ptr_a + hdr_off, (h, w, 4), torch.float32)
+            assert torch.equal(seen_by_exporter.view(torch.int32), ref_hdr.view(torch.int32))
+        torch.cuda.synchronize()
+    finally:
+        lp.release_external_memory(mem_b)
+        lp.release_external_memory(mem_a)
+    with pytest.raises(lighting.MilError):
+        lp.import_external_memory(-1, 4096)
+
+
 def test_shade_frame_equals_subpass_chain(lp):
     """mil_shade_frame (one launch) == mil_light_ex(HDR) -> mil_sky_hosek -> mil_transparency_resolve -> mil_tonemap,
     bit for bit in both numeric modes, on the streaming (no point lights) and the tiled kernel, whole frame and strip."""
