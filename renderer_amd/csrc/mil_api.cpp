@@ -63,6 +63,7 @@ struct mil_ctx {
     uint8_t row_key[176];
     bool row_key_valid = false;
     uint32_t tonemap_rows = 0;   // K4 rows per lane (env MIL_TONEMAP_ROWS; tuning only)
+    uint32_t fxaa_rows = 2;      // K5 output rows per lane: 2 or 4 (env MIL_FXAA_ROWS; tuning only)
     uint32_t k1_rows = 1;   // K1 pixels per lane: 1 or 4 (env MIL_K1_ROWS overrides; tuning only)
     int last_hip = 0;
 };
@@ -350,6 +351,7 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
     c->max_point = max_point_lights;
     if (const char *e = getenv("MIL_TUNE")) c->tune = (uint32_t)atoi(e);
     if (const char *e = getenv("MIL_TONEMAP_ROWS")) c->tonemap_rows = (uint32_t)atoi(e);
+    if (const char *e = getenv("MIL_FXAA_ROWS")) c->fxaa_rows = atoi(e) == 4 ? 4u : 2u;
     if (const char *e = getenv("MIL_K1_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->k1_rows = (uint32_t)v; }
     c->slot_bytes = 2 * (size_t)MIL_MAX_DIR_LIGHTS * 32 + (size_t)max_point_lights * (32 + 32 + 16);
     int rc = set_device(c);
@@ -546,6 +548,7 @@ int mil_fxaa(mil_ctx *c, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t wi
     p.ldr = ldr; p.out = out; p.width = width; p.height = height; p.ldr_pitch = ldr_pitch_px; p.out_pitch = out_pitch_px;
     p.row_begin = row_begin; p.row_count = row_count;
     p.lut11 = c->lut; p.lut10 = c->lut + LUT11_N;
+    p.rows = c->fxaa_rows;
     if (flags & MIL_FLAG_STRICT) mil::strict::launch_fxaa(p, (hipStream_t)stream);
     else mil::fast::launch_fxaa(p, (hipStream_t)stream);
     return finish(c, nullptr, (hipStream_t)stream);

@@ -1471,64 +1471,74 @@ __global__ __launch_bounds__(256) void k_fxaa(const FxaaParams p)
 }
 
 #if !MIL_STRICT
-// Fast FXAA: each lane owns ONE column and TWO output rows (y, y + 1); it decodes the four texels of its column
-// in rows y - 1 .. y + 2 once, and the diagonal neighbours' lumas come from lanes l - 1 / l + 1 by DPP wave
+// Fast FXAA: each lane owns ONE column and R output rows (y .. y + R - 1; R = 2 or 4); it decodes the R + 2 texels of
+// its column in rows y - 1 .. y + R once, and the diagonal neighbours' lumas come from lanes l - 1 / l + 1 by DPP wave
 // shifts instead of four more loads + decodes each.  Lanes 0 and 63 are halo lanes (columns x0 - 1, x0 + 62), so
-// a wave produces 62 columns.  Per-pixel arithmetic is float2 (packed).  Same texel picks as k_fxaa.
+// a wave produces 62 columns.  Per-pixel arithmetic is float2 (packed, row pairs).  Same texel picks as k_fxaa.
 template <int CTRL> DEV float wave_shift(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
+template <int R>
 __global__ __launch_bounds__(256) void k_fxaa2(const FxaaParams p)
 {
     const int lane = (int)threadIdx.x;
     const int col = (int)(blockIdx.x * 62) + lane - 1;                 // may be -1 or >= width: clamp to edge
     // the wave's rows are wave-uniform: row clamps and row base addresses are scalar work, the lane adds its column
-    const uint32_t yy = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.y * 4 + threadIdx.y) * 2));   // first of the two rows, strip-local
+    const uint32_t yy = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.y * 4 + threadIdx.y) * R));   // first of the R rows, strip-local
     if (yy >= p.row_count) return;                                      // whole wave
     const int y = (int)(p.row_begin + yy);
     const int xc = min(max(col, 0), (int)p.width - 1), H1 = (int)p.height - 1;
-    f3 c[4];
-    float L[4];
-    uint32_t u[4];
+    f3 c[R + 2];
+    float L[R + 2];
+    uint32_t u[R + 2];
 #pragma unroll
-    for (int r = 0; r < 4; r++) u[r] = (p.ldr + (size_t)min(max(y - 1 + r, 0), H1) * p.ldr_pitch)[(uint32_t)xc];
+    for (int r = 0; r < R + 2; r++) u[r] = (p.ldr + (size_t)min(max(y - 1 + r, 0), H1) * p.ldr_pitch)[(uint32_t)xc];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < R + 2; r++) {
         c[r] = fxaa_decode(u[r]);
         L[r] = fxaa_luma(c[r]);
     }
     // A pixel whose edge direction is shorter than one pixel keeps its centre texel (below), which is an R11G11B10F
     // code: its sRGB8 value comes from the two tables of every code <= 1.0 (exact, the tonemap's VIA_LDR tables)
     // instead of three log/exp evaluations.  Per pixel, not per wave, so a strip equals the rows of the whole frame.
-    uint32_t wl[2];
+    uint32_t wl[R];
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
+    for (int e = 0; e < R; e++) {
         const uint32_t t = u[1 + e];
         wl[e] = (uint32_t)p.lut10[min(t >> 22, 0x1E0u)] | ((uint32_t)p.lut11[min((t >> 11) & 0x7FFu, 0x3C0u)] << 8) |
                 ((uint32_t)p.lut11[min(t & 0x7FFu, 0x3C0u)] << 16) | 0xFF000000u;
     }
-    float Lw[4], Le[4];                                                  // the same rows, one column to the west / east
+    float Lw[R + 2], Le[R + 2];                                          // the same rows, one column to the west / east
 #pragma unroll
-    for (int r = 0; r < 4; r++) { Lw[r] = wave_shift<0x138>(L[r]); Le[r] = wave_shift<0x130>(L[r]); }   // wave_shr:1 / wave_shl:1
+    for (int r = 0; r < R + 2; r++) { Lw[r] = wave_shift<0x138>(L[r]); Le[r] = wave_shift<0x130>(L[r]); }   // wave_shr:1 / wave_shl:1
     const float KRED = 0.03125f, REDUCE_MIN = 0.0078125f, SPAN = 8.0f;
     const float K1 = (float)(1.0 / 3.0 - 0.5), K2 = (float)(2.0 / 3.0 - 0.5);
-    const v2f lNW = { Lw[0], Lw[1] }, lNE = { Le[0], Le[1] }, lSW = { Lw[2], Lw[3] }, lSE = { Le[2], Le[3] }, lM = { L[1], L[2] };
-    const v2f lmin = { fminf(lM.x, fminf(fminf(lNW.x, lNE.x), fminf(lSW.x, lSE.x))), fminf(lM.y, fminf(fminf(lNW.y, lNE.y), fminf(lSW.y, lSE.y))) };
-    const v2f lmax = { fmaxf(lM.x, fmaxf(fmaxf(lNW.x, lNE.x), fmaxf(lSW.x, lSE.x))), fmaxf(lM.y, fmaxf(fmaxf(lNW.y, lNE.y), fmaxf(lSW.y, lSE.y))) };
-    v2f dx = (lSW + lSE) - (lNW + lNE), dy = (lNW + lSW) - (lNE + lSE);
-    const v2f red = max_((lNW + lNE + lSW + lSE) * KRED, (v2f)(REDUCE_MIN));
-    const v2f rcpmin = rcp_(v2f{ fminf(fabsf(dx.x), fabsf(dy.x)), fminf(fabsf(dx.y), fabsf(dy.y)) } + red);
-    dx = med3_(dx * rcpmin, -SPAN, SPAN);
-    dy = med3_(dy * rcpmin, -SPAN, SPAN);
     const bool live = lane >= 1 && lane <= 62 && col < (int)p.width;
-    f3 o[2] = { c[1], c[2] };
-    const bool edge0 = fmaxf(fabsf(dx.x), fabsf(dy.x)) > 0.99f, edge1 = fmaxf(fabsf(dx.y), fabsf(dy.y)) > 0.99f;
-    if (__builtin_amdgcn_ballot_w64(live && (edge0 || edge1)) != 0) {
+    float dxs[R], dys[R], mns[R], mxs[R];
+    bool edge[R];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            if (__builtin_amdgcn_ballot_w64(live && (e ? edge1 : edge0)) == 0) continue;   // this row of the wave has no edge
-            const float ddx = e ? dx.y : dx.x, ddy = e ? dy.y : dy.x;
+    for (int j = 0; j < R; j += 2) {                                     // output rows j, j + 1 as one float2
+        const v2f lNW = { Lw[j], Lw[j + 1] }, lNE = { Le[j], Le[j + 1] }, lSW = { Lw[j + 2], Lw[j + 3] }, lSE = { Le[j + 2], Le[j + 3] };
+        const v2f lM = { L[j + 1], L[j + 2] };
+        mns[j] = fminf(lM.x, fminf(fminf(lNW.x, lNE.x), fminf(lSW.x, lSE.x))); mns[j + 1] = fminf(lM.y, fminf(fminf(lNW.y, lNE.y), fminf(lSW.y, lSE.y)));
+        mxs[j] = fmaxf(lM.x, fmaxf(fmaxf(lNW.x, lNE.x), fmaxf(lSW.x, lSE.x))); mxs[j + 1] = fmaxf(lM.y, fmaxf(fmaxf(lNW.y, lNE.y), fmaxf(lSW.y, lSE.y)));
+        v2f dx = (lSW + lSE) - (lNW + lNE), dy = (lNW + lSW) - (lNE + lSE);
+        const v2f red = max_((lNW + lNE + lSW + lSE) * KRED, (v2f)(REDUCE_MIN));
+        const v2f rcpmin = rcp_(v2f{ fminf(fabsf(dx.x), fabsf(dy.x)), fminf(fabsf(dx.y), fabsf(dy.y)) } + red);
+        dx = med3_(dx * rcpmin, -SPAN, SPAN);
+        dy = med3_(dy * rcpmin, -SPAN, SPAN);
+        dxs[j] = dx.x; dxs[j + 1] = dx.y; dys[j] = dy.x; dys[j + 1] = dy.y;
+        edge[j] = fmaxf(fabsf(dx.x), fabsf(dy.x)) > 0.99f; edge[j + 1] = fmaxf(fabsf(dx.y), fabsf(dy.y)) > 0.99f;
+    }
+    bool any_edge = false;
+#pragma unroll
+    for (int e = 0; e < R; e++) any_edge = any_edge || edge[e];
+    if (__builtin_amdgcn_ballot_w64(live && any_edge) != 0) {
+#pragma unroll
+        for (int e = 0; e < R; e++) {
+            if (__builtin_amdgcn_ballot_w64(live && edge[e]) == 0) continue;   // this row of the wave has no edge
+            const float ddx = dxs[e], ddy = dys[e];
             const float fx = (float)col + 0.5f, fy = (float)(y + e) + 0.5f;
             auto tap = [&](float k) {          // pixel offsets fit 30 bits (checked on the host): one 24-bit mad + scalar base
                 const int ix = min(max((int)floorf(__builtin_fmaf(ddx, k, fx)), 0), (int)p.width - 1);
@@ -1541,15 +1551,15 @@ __global__ __launch_bounds__(256) void k_fxaa2(const FxaaParams p)
             const f3 a = { 0.5f * (t0.x + t1.x), 0.5f * (t0.y + t1.y), 0.5f * (t0.z + t1.z) };
             const f3 b = { __builtin_fmaf(0.25f, t2.x + t3.x, a.x * 0.5f), __builtin_fmaf(0.25f, t2.y + t3.y, a.y * 0.5f),
                            __builtin_fmaf(0.25f, t2.z + t3.z, a.z * 0.5f) };
-            const float lB = fxaa_luma(b), mn = e ? lmin.y : lmin.x, mx = e ? lmax.y : lmax.x;
-            o[e] = (lB < mn || lB > mx) ? a : b;
-            const uint32_t w = srgb8_direct(sat(o[e].z)) | (srgb8_direct(sat(o[e].y)) << 8) | (srgb8_direct(sat(o[e].x)) << 16) | 0xFF000000u;
-            if (e ? edge1 : edge0) wl[e] = w;
+            const float lB = fxaa_luma(b);
+            const f3 o = (lB < mns[e] || lB > mxs[e]) ? a : b;
+            const uint32_t w = srgb8_direct(sat(o.z)) | (srgb8_direct(sat(o.y)) << 8) | (srgb8_direct(sat(o.x)) << 16) | 0xFF000000u;
+            if (edge[e]) wl[e] = w;
         }
     }
     if (!live) return;
 #pragma unroll
-    for (int e = 0; e < 2; e++) {
+    for (int e = 0; e < R; e++) {
         if (yy + e >= p.row_count) break;
         __builtin_nontemporal_store(wl[e], (p.out + (size_t)(yy + e) * p.out_pitch) + (uint32_t)col);
     }
@@ -1753,8 +1763,13 @@ void launch_fxaa(const FxaaParams &p, hipStream_t s)
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.row_count + 3) / 4);
     hipLaunchKernelGGL(k_fxaa, grid, block, 0, s, p);
 #else
-    dim3 block(64, 4), grid((p.width + 61) / 62, (p.row_count + 7) / 8);
-    hipLaunchKernelGGL(k_fxaa2, grid, block, 0, s, p);
+    if (p.rows == 2) {
+        dim3 block(64, 4), grid((p.width + 61) / 62, (p.row_count + 7) / 8);
+        hipLaunchKernelGGL(k_fxaa2<2>, grid, block, 0, s, p);
+    } else {
+        dim3 block(64, 4), grid((p.width + 61) / 62, (p.row_count + 15) / 16);
+        hipLaunchKernelGGL(k_fxaa2<4>, grid, block, 0, s, p);
+    }
 #endif
 }
 void launch_sky(const SkyParams &p, hipStream_t s)

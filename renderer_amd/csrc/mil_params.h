@@ -67,6 +67,7 @@ struct FxaaParams {
     uint32_t *out;              // rows [row_begin, row_begin + row_count), B8G8R8A8_SRGB
     uint32_t width, height, ldr_pitch, out_pitch, row_begin, row_count;
     const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
+    uint32_t rows;              // fast kernel: output rows per lane, 2 or 4 (tuning; 0 = default)
 };
 
 struct SkyParams {            // sky subpass: depth in, hdr in/out
