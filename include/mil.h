@@ -15,6 +15,7 @@
  * (mirrors the reference's per-frame CpuBufferPool ring, render/pools.rs:42-57).
  * Calls enqueue work on `stream` (a hipStream_t, 0 = default stream) and return;
  * no per-frame call allocates after mil_create (the external-memory set-up calls below do).  One context = one thread at a time.
+ * Every call makes the context's device the calling thread's current HIP device and leaves it so.
  * All functions return 0 on success or a negative mil_status; nothing aborts.
  */
 #ifndef MIL_H
