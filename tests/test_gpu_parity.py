@@ -548,7 +548,12 @@ def test_external_memory_hand_over(lp):
     gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=24, shadow=128)
     px = w * h
     need = px * (4 * 4 + 16 + 4 + 4)
-    mem_a, ptr_a, fd, size = lp.alloc_exportable_memory(need)
+    try:
+        mem_a, ptr_a, fd, size = lp.alloc_exportable_memory(need)
+    except lighting.MilError as e:
+        if '(hip 801)' in str(e):                               # hipErrorNotSupported: this driver cannot export dma-bufs
+            pytest.skip('the HIP driver of this box does not export device memory as a POSIX fd')
+        raise
     assert size >= need and fd >= 0
     mem_b, ptr_b = lp.import_external_memory(fd, size)
     os.close(fd)                                                # both sides hold their own reference now
