@@ -569,7 +569,8 @@ DEV void sky_radiance(const PRM &p, uint32_t x, uint32_t y, float d, float r3[3]
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float t = __builtin_fmaf(-2.0f * H[c], cg, __builtin_fmaf(H[c], H[c], 1.0f));       // 1 + H^2 - 2 H cos(gamma)
-        const float chi = (1.0f + cg2) * rsq_(t) * rcp_(t);                                       // t^-1.5
+        const float rt = rsq_(t);
+        const float chi = (1.0f + cg2) * (rt * rt * rt);                                          // t^-1.5 with one transcendental
         const float left = __builtin_fmaf(A[c], __builtin_amdgcn_exp2f(B[c] * ict * LOG2E), 1.0f);
         const float right = __builtin_fmaf(I[c], sct, __builtin_fmaf(G[c], chi, __builtin_fmaf(F[c], cg2,
                             __builtin_fmaf(D[c], __builtin_amdgcn_exp2f(E[c] * gamma * LOG2E), C[c]))));
