@@ -842,3 +842,17 @@ def test_strict_kernels_vs_executed_reference_shaders(lp):
     enc = mo.encode_b8g8r8a8_srgb(ref['fxaa_color'][..., :3].astype(np.float64))
     got = lp.fxaa(torch.from_numpy(f['ldr'].view(np.int32)).to(DEV), strict=True).cpu().numpy().view(np.uint32)
     np.testing.assert_array_equal(got, enc)
+
+
+def test_randomised_sweep(lp):
+    """Sixty configurations of tools/fuzz_parity.py (random frame size, strip, pitch, light counts, shadow size, flags, output
+    format): strict == C oracle, culled == brute force, mil_shade_frame == the chain of calls, FXAA strip == whole-frame rows,
+    accumulate == C oracle, all bit for bit; fast within the documented tolerance.  The tool runs thousands of these."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_parity
+    fuzz_parity.coracle.build()
+    fails = []
+    for seed in range(1000, 1060):
+        fails += fuzz_parity.one(lp, seed)
+    assert not fails, fails
