@@ -9,7 +9,7 @@ O=gpurun_out/prof_$R
 mkdir -p $O
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  for k in headline k1; do
+  for k in headline k1 accumulate; do
     timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${k}_$c -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_$c.log 2>&1
   done
 done

@@ -14,6 +14,11 @@ frame = cam.frame_matrix_data(); dl = ubo.default_directional_lights(); pl = syn
 sh = synth.shadow_setup(dl[0, :3], 2048, device=dev); amb = (0.03,) * 3
 hdrs = [torch.empty((H, W, 4), device=dev) for _ in range(3)]
 outs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(3)]
+frs = None
+if case == 'accumulate':
+    fr = synth.transparent_fragments(W * H, seed=7)
+    frs = [{k: torch.from_numpy(v).to(dev) for k, v in fr.items()} for _ in range(2)]
+    acc = [torch.empty((W * H, 4), device=dev) for _ in range(2)]; rev = [torch.empty((W * H,), device=dev) for _ in range(2)]
 ldrs = [lp.tonemap(lp.light_ex(gbs[0], frame, dl, pl, amb, sh), 1) for _ in range(3)] if case == 'fxaa' else None
 torch.cuda.synchronize()
 for i in range(iters):
@@ -28,5 +33,6 @@ for i in range(iters):
     elif case == 'points': lp.light_ex(gbs[k], frame, dl[:0], pl, None, None, out=hdrs[k])
     elif case == 'tonemap': lp.tonemap(hdrs[k], 2, out=outs[k])
     elif case == 'fxaa': lp.fxaa(ldrs[k], out=outs[k])
+    elif case == 'accumulate': lp.transparency_accumulate(frs[i % 2], frame, dl, accum=acc[i % 2], reveal=rev[i % 2])
     else: raise SystemExit('unknown case')
 torch.cuda.synchronize()
