@@ -247,6 +247,30 @@ DEV v2f rcp_(v2f x) { return v2f{ rcp_(x.x), rcp_(x.y) }; }
 DEV v2f rsq_(v2f x) { return v2f{ rsq_(x.x), rsq_(x.y) }; }
 DEV v2f sqrt_(v2f x) { return v2f{ sqrt_(x.x), sqrt_(x.y) }; }
 DEV v2f sat(v2f x) { return v2f{ sat(x.x), sat(x.y) }; }
+// Saturate folded into the packed multiply / fma that produces the value (the clamp bit of VOP3P; the compiler only folds it
+// into scalar-FP32 producers and otherwise spends two v_max per pair).  The s_nop on either side is the wait state the
+// compiler keeps between a packed-FP32 write and the VALU instruction that reads it, which it cannot place around inline asm.
+DEV v2f sat_mul(v2f a, v2f b)
+{
+    v2f d;
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 clamp\n\ts_nop 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+DEV v2f sat_fma(v2f a, v2f b, v2f c)
+{
+    v2f d;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 clamp\n\ts_nop 0" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+DEV v2f sat_fnma(v2f a, v2f b, v2f c)      // sat(c - a * b)
+{
+    v2f d;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\ts_nop 0" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+DEV float sat_mul(float a, float b) { return sat(a * b); }
+DEV float sat_fma(float a, float b, float c) { return sat(__builtin_fmaf(a, b, c)); }
+DEV float sat_fnma(float a, float b, float c) { return sat(__builtin_fmaf(-a, b, c)); }
 DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 DEV v2f fma_(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 DEV float max_(float a, float b) { return fmaxf(a, b); }
@@ -351,14 +375,14 @@ template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> col, T
     // L = -V (light straight behind the pixel as seen from the camera): H = 0 and normalize(H) is NaN in the literal
     // shader; here |H|^2 is floored, N.H and L.H come out 0 and the term dies with N.L = 0 as it should
     T rh = rsq_(max_(dot3(H, H), (T)(1e-30f)));
-    eval_tail<T>(q, sat(dot3(q.N, L)), sat(dot3(q.N, H) * rh), sat(dot3(L, H) * rh), col, scale, res);
+    eval_tail<T>(q, sat_fma(q.N.z, L.z, fma_(q.N.y, L.y, q.N.x * L.x)), sat_mul(dot3(q.N, H), rh), sat_mul(dot3(L, H), rh), col, scale, res);
 }
 // |L| = 1 (point lights, normalised here):  |L+V|^2 = 2 + 2 L.V,  N.H = (N.L + N.V) / |L+V|,  L.H = (1 + L.V) / |L+V|
 template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
     T nl = dot3(q.N, L), lv = dot3(L, q.V);
     T rh = rsq_(max_(fma_((T)2.0f, lv, (T)2.0f), (T)(1e-30f)));     // L = -V: see eval_light
-    eval_tail<T>(q, sat(nl), sat((nl + q.NdotVraw) * rh), sat(fma_(lv, rh, rh)), col, scale, res);
+    eval_tail<T>(q, sat(nl), sat_mul(nl + q.NdotVraw, rh), sat_fma(lv, rh, rh), col, scale, res);
 }
 
 DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
@@ -415,7 +439,7 @@ DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1
 {
     v2f inv = rsq_(d2 + 1e-12f);
     V3<v2f> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
-    v2f qq = d2 * b.w, w = sat(fma_(-qq, qq, (v2f)(1.0f)));
+    v2f qq = d2 * b.w, w = sat_fnma(qq, qq, (v2f)(1.0f));
     v2f att = (w * w) * rcp_(d2 + 1e-4f);
     att = v2f{ on0 ? att.x : 0.0f, on1 ? att.y : 0.0f };          // see point_eval
     eval_light_unit<v2f>(q, L, V3<v2f>{ (v2f)(b.x), (v2f)(b.y), (v2f)(b.z) }, att, res);
