@@ -81,7 +81,6 @@ template <typename T> struct PxT {
     V3<T> N, V, P;
     T occ;
     T alpha, a2, am1, NdotV, sV;       // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
-    T NdotVraw;                        // dot(N, V) before the clamp (point lights: N.H = (N.L + N.V) / |L + V|)
     V3<T> G0, G1;                      // tint * F0, tint * (f90 - F0), tint = ((1-m) + albedo*m)*occ
     V3<T> dif;                         // albedo/PI*(1-m)*occ
 };
@@ -330,8 +329,7 @@ template <typename T, typename U> DEV void setup_pixel_t(PxT<T> &q, const PosT<T
     q.alpha = roughness * roughness;
     q.a2 = q.alpha * q.alpha;
     q.am1 = q.a2 - 1.0f;
-    q.NdotVraw = dot3(q.N, q.V);
-    q.NdotV = med3_(q.NdotVraw, 0.0001f, 1.0f);
+    q.NdotV = med3_(dot3(q.N, q.V), 0.0001f, 1.0f);
     q.sV = sqrt_(fma_(fma_(-q.a2, q.NdotV, q.NdotV), q.NdotV, q.a2));
     T om = 1.0f - m;
     const V3<T> F0 = { fma_(albedo.x, m, 0.04f * om), fma_(albedo.y, m, 0.04f * om), fma_(albedo.z, m, 0.04f * om) };
@@ -377,12 +375,13 @@ template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> col, T
     T rh = rsq_(max_(dot3(H, H), (T)(1e-30f)));
     eval_tail<T>(q, sat_fma(q.N.z, L.z, fma_(q.N.y, L.y, q.N.x * L.x)), sat_mul(dot3(q.N, H), rh), sat_mul(dot3(L, H), rh), col, scale, res);
 }
-// |L| = 1 (point lights, normalised here):  |L+V|^2 = 2 + 2 L.V,  N.H = (N.L + N.V) / |L+V|,  L.H = (1 + L.V) / |L+V|
+// Point lights (L normalised here) take the same literal H = L + V.  The unit-length shortcut |L+V|^2 = 2 + 2 L.V,
+// N.H = (N.L + N.V) / |L+V| is six packed instructions per pair shorter (-5 % on the headline frame) but cancels when the
+// light is nearly opposite the eye (L.V -> -1): N.H lost up to ten bits there, 7 % on a mirror-like grazing highlight
+// (one pixel in ~1e8 of tools/fuzz_parity.py's random frames; the literal form has none).
 template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
-    T nl = dot3(q.N, L), lv = dot3(L, q.V);
-    T rh = rsq_(max_(fma_((T)2.0f, lv, (T)2.0f), (T)(1e-30f)));     // L = -V: see eval_light
-    eval_tail<T>(q, sat(nl), sat_mul(nl + q.NdotVraw, rh), sat_fma(lv, rh, rh), col, scale, res);
+    eval_light<T>(q, L, col, scale, res);
 }
 
 DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
