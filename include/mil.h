@@ -14,7 +14,9 @@
  * uniform struct / light array pointer is HOST memory, copied during the call
  * (mirrors the reference's per-frame CpuBufferPool ring, render/pools.rs:42-57).
  * Calls enqueue work on `stream` (a hipStream_t, 0 = default stream) and return;
- * no per-frame call allocates after mil_create (the external-memory set-up calls below do).  One context = one thread at a time.
+ * no per-frame call allocates after mil_create (the external-memory set-up calls below do).  One context = one thread at a time;
+ * calls of one context may name different streams (the staged light copies are tracked per stream: up to four streams
+ * per light set run unthrottled, a fifth waits for the oldest).
  * Every call makes the context's device the calling thread's current HIP device and leaves it so.
  * All functions return 0 on success or a negative mil_status; nothing aborts.
  */
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIL_VERSION 1
+#define MIL_VERSION 2
 #define MIL_MAX_DIR_LIGHTS 100u /* MAX_LIGHTS, renderer/shaders/inc_structs.glsl:1; pool render/pbr/mod.rs:36 */
 #define MIL_TILE 16u            /* screen tile edge of the culled path */
 
@@ -38,7 +40,8 @@ typedef enum mil_status {
     MIL_ERR_TOO_MANY_LIGHTS = -2, /* the reference panics here (render/mod.rs:197-199); we return */
     MIL_ERR_HIP = -3,             /* a HIP runtime call failed; mil_last_hip_error() has the code */
     MIL_ERR_NO_DEVICE = -4,
-    MIL_ERR_CAPACITY = -5         /* more point lights than the context was created for */
+    MIL_ERR_CAPACITY = -5,        /* more point lights than the context was created for */
+    MIL_ERR_RCCL = -6             /* an RCCL call failed or librccl is missing; mil_mg_last_rccl_error() has the code */
 } mil_status;
 
 /* FrameMatrixData — renderer/src/render/ubo.rs:28-41; GLSL block
@@ -234,6 +237,27 @@ int mil_shade_frame(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     const mil_extras *extras, const mil_frame_passes *passes, void *out, uint32_t out_pitch_px,
                     mil_out_format fmt, uint32_t flags, void *stream);
 
+/* Band dealing (SURVEY.md 8 e, multi-GPU strips): instead of one contiguous strip, a rank holds every n_ranks-th band
+ * of band_rows rows of the frame, compacted: local row k of the planes is frame row
+ *     ((k / band_rows) * n_ranks + rank) * band_rows + k % band_rows.
+ * Dealt bands equalise the cost of the ranks without a calibration frame (a contiguous strip of the floor costs a
+ * multiple of a strip of sky).  band_rows: a power of two >= 16 (a 16x16 tile never straddles two bands). */
+typedef struct mil_band_layout {
+    uint32_t band_rows, n_ranks, rank;
+} mil_band_layout;
+
+/* mil_shade_frame on a rank's dealt bands (no counterpart in the reference, which has one device: render/vulkan.rs:106-108).
+ * gb: the rank's compacted planes (gb->height local rows; gb->y_offset must be 0), push->resolution the whole frame.
+ * out: the rank's compacted output (out_is_frame = 0) or the assembled frame, written at frame rows (out_is_frame = 1:
+ * how rank 0 of a gather avoids a copy).  passes->accum / reveal, when given, are compacted like the planes.
+ * Every pixel equals the monolithic mil_shade_frame pixel bit for bit.  bands = NULL: same as mil_shade_frame. */
+int mil_shade_bands(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                    const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *extras,
+                    const mil_frame_passes *passes, const mil_band_layout *bands, void *out, uint32_t out_pitch_px,
+                    int out_is_frame, mil_out_format fmt, uint32_t flags, void *stream);
+/* Local rows rank `rank` holds of a frame of `height` rows under `bands` (host arithmetic only). */
+uint32_t mil_band_local_rows(const mil_band_layout *bands, uint32_t height);
+
 /* NEXT ROW, the HIP half of the Vulkan <-> HIP hand-over.  The reference's attachments are Vulkan
  * images (render/pbr/mod.rs:76-95,150-160); to be read or written by this library their memory must be one allocation
  * visible to both APIs.  Either direction works through a POSIX fd (on amdgpu a dma-buf):
@@ -256,11 +280,18 @@ int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     unsigned long long *count, void *stream);
 
 /* After a culled mil_light_ex: per-tile light-list lengths of that call are written to
- * `counts` (DEVICE, tiles_x * tiles_y uint32) when set before the call; NULL disables. */
-int mil_set_tile_count_buffer(mil_ctx *ctx, uint32_t *counts);
+ * `counts` (DEVICE, n_tiles uint32) when set before the call; NULL disables.  A launch with more than n_tiles
+ * tiles (tiles_x * tiles_y) leaves the buffer untouched. */
+int mil_set_tile_count_buffer(mil_ctx *ctx, uint32_t *counts, uint32_t n_tiles);
 /* Diagnostics: per tile {start, end} in 100 MHz ticks (low 32 bits), list length, HW_ID of the shading wave.
- * stamps: DEVICE, 4 * tiles_x * tiles_y uint32; NULL disables. */
-int mil_set_tile_stamp_buffer(mil_ctx *ctx, uint32_t *stamps);
+ * stamps: DEVICE, 4 * n_tiles uint32; NULL disables; larger launches leave it untouched. */
+int mil_set_tile_stamp_buffer(mil_ctx *ctx, uint32_t *stamps, uint32_t n_tiles);
+/* Diagnostics, host arithmetic only (no GPU): the scheduling weight of every 16-row tile row of a culled launch =
+ * the number of point lights whose bounding sphere projects onto it (rows are launched in descending weight; speed
+ * only).  weights: HOST, ceil(gb_height / 16) uint32.  bands may be NULL. */
+int mil_row_weights(const mil_frame_matrix_data *frame, const mil_push_constants *push, uint32_t gb_height,
+                    uint32_t y_offset, const mil_band_layout *bands, const mil_point_light *point_lights,
+                    uint32_t n_point, uint32_t *weights);
 
 int mil_sync(mil_ctx *ctx, void *stream);
 int mil_last_hip_error(const mil_ctx *ctx);

@@ -15,8 +15,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, 'mil_oracle.c')
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ('mil_oracle.c', 'mil_oracle_f64.c', 'Makefile'))
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < newest:
         subprocess.check_call(['make', '-C', _HERE, '-B', 'libmil_oracle.so'], stdout=subprocess.DEVNULL)
 
 
@@ -69,6 +69,36 @@ def shade(normal, albedo_occ, rough_metal, depth, frame_ubo, dir_lights, width=N
     if width is not None and width != w:
         raise ValueError('strips are full-width')
     return (hdr, pairs.value) if return_pairs else hdr
+
+
+def shade_f64(normal, albedo_occ, rough_metal, depth, frame_ubo, dir_lights, full_height=None, y_offset=0,
+              point_lights=None, ambient=None, shadow=None, want_cond=False, nthreads=0):
+    """oracle.mil_oracle.shade (float64) in C + OpenMP (oracle/mil_oracle_f64.c): whole 4K frames in seconds.
+    Returns hdr (h, w, 4) float64 [, cond (h, w, 3) float64]."""
+    h, w = depth.shape
+    c = np.ascontiguousarray
+    normal, albedo_occ, rough_metal = (c(normal, np.uint32), c(albedo_occ, np.uint32), c(rough_metal, np.uint32))
+    depth = c(depth, np.float32)
+    ubo = c(frame_ubo, np.float32).reshape(68)
+    dl = c(dir_lights, np.float32).reshape(-1, 8) if dir_lights is not None else np.zeros((0, 8), np.float32)
+    pl = c(point_lights, np.float32).reshape(-1, 8) if point_lights is not None else np.zeros((0, 8), np.float32)
+    amb = c(ambient, np.float32) if ambient is not None else None
+    lvp = smap = None
+    ssize, sbias = 0, 0.0
+    if shadow is not None:
+        lvp = c(shadow['light_view_proj'], np.float32)
+        smap = c(np.asarray(shadow['map']), np.float32)
+        ssize, sbias = smap.shape[0], float(shadow['bias'])
+    hdr = np.empty((h, w, 4), np.float64)
+    cond = np.empty((h, w, 3), np.float64) if want_cond else None
+    f, u, d = ctypes.c_float, ctypes.c_uint32, ctypes.c_double
+    lib().milo_shade_f64(_p(normal, u), _p(albedo_occ, u), _p(rough_metal, u), _p(depth, f),
+                         ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(y_offset),
+                         ctypes.c_int(h if full_height is None else full_height),
+                         _p(ubo, f), _p(dl, f), ctypes.c_int(dl.shape[0]), _p(pl, f), ctypes.c_int(pl.shape[0]),
+                         _p(amb, f), _p(lvp, f), _p(smap, f), ctypes.c_int(ssize), ctypes.c_float(sbias),
+                         _p(hdr, d), _p(cond, d), ctypes.c_int(nthreads))
+    return (hdr, cond) if want_cond else hdr
 
 
 def tonemap(hdr, fmt, nthreads=0):

@@ -10,8 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../../include/mil.h"
-#include "mil_params.h"
+#include "mil_internal.h"
 
 static_assert(sizeof(mil_frame_matrix_data) == 272, "FrameMatrixData is 272 bytes (render/ubo.rs:28-41)");
 static_assert(sizeof(mil_directional_light) == 32, "DirectionalLight std140 stride is 32 (render/ubo.rs:54-63)");
@@ -19,22 +18,7 @@ static_assert(sizeof(mil_point_light) == 32, "point light shares the 32-byte str
 static_assert(sizeof(mil_hosek_wilkie_params) == 176, "HosekWilkieParams is 11 vec3 at 16-byte stride (render/hosek/mod.rs:222-256)");
 static_assert(sizeof(mil_push_constants) == 12, "push constants are 12 bytes (fs_deferred_lighting.glsl:24-27)");
 
-namespace {
-
-constexpr int RING = 4;
-constexpr uint32_t LUT11_N = 0x3C1, LUT10_N = 0x1E1;
-
-struct Slot {
-    uint8_t *host = nullptr; // pinned
-    uint8_t *dev = nullptr;
-    hipEvent_t done = nullptr;   // last kernel that read this slot
-    hipEvent_t staged = nullptr; // upload of this slot's content finished (recorded on the copy stream)
-    bool used = false;
-    uint32_t n_dir = 0, n_point = 0;
-    uint64_t gen = 0;            // bumped whenever new content is staged into this slot
-};
-
-} // namespace
+using namespace milhost;
 
 struct mil_external_memory {
     bool imported = false;
@@ -46,40 +30,31 @@ struct mil_external_memory {
     bool have_handle = false, is_mapped = false;
 };
 
-struct mil_ctx {
-    int device = 0;
-    uint32_t max_point = 0;
-    size_t slot_bytes = 0;
-    Slot ring[RING];
-    int next = 0, cur = -1;      // cur: slot holding the most recently staged content
-    uint64_t gen = 0;
-    uint8_t *scratch = nullptr;  // host: the content of this call, built before it is compared with slot `cur`
-    hipStream_t copy_stream = nullptr;
-    uint8_t *lut = nullptr; // device: lut11 then lut10
-    uint32_t *tile_counts = nullptr;
-    uint32_t *tile_stamps = nullptr;
-    uint32_t tune = 0;
-    uint16_t row_order[MIL_MAX_ROW_ORDER];   // last computed K2 row order and what it was computed from (order_rows)
-    uint8_t row_key[176];
-    bool row_key_valid = false;
-    uint32_t tonemap_rows = 0;   // K4 rows per lane (env MIL_TONEMAP_ROWS; tuning only)
-    uint32_t fxaa_rows = 2;      // K5 output rows per lane: 2 or 4 (env MIL_FXAA_ROWS; tuning only)
-    uint32_t k1_rows = 1;   // K1 pixels per lane: 1 or 4 (env MIL_K1_ROWS overrides; tuning only)
-    int last_hip = 0;
-};
-
-namespace {
+namespace milhost {
 
 int hip_fail(mil_ctx *c, hipError_t e)
 {
     if (c) c->last_hip = (int)e;
     return MIL_ERR_HIP;
 }
+
+int set_device(mil_ctx *c)
+{
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess && cur != c->device) e = hipSetDevice(c->device);
+    return e == hipSuccess ? MIL_OK : hip_fail(c, e);
+}
+
+} // namespace milhost
+
 #define HIP_TRY(c, expr)                                    \
     do {                                                    \
         hipError_t e_ = (expr);                             \
         if (e_ != hipSuccess) return hip_fail((c), e_);     \
     } while (0)
+
+namespace {
 
 double ufloat_dec(uint32_t code, int mbits)
 {
@@ -94,15 +69,19 @@ uint8_t srgb8(double c)
     return (uint8_t)floor(s * 255.0 + 0.5);
 }
 
-int set_device(mil_ctx *c)
+bool bands_ok(const mil_band_layout *b)
 {
-    int cur = -1;
-    HIP_TRY(c, hipGetDevice(&cur));
-    if (cur != c->device) HIP_TRY(c, hipSetDevice(c->device));
-    return MIL_OK;
+    return b->band_rows >= MIL_TILE && (b->band_rows & (b->band_rows - 1u)) == 0 && b->band_rows <= (1u << 20) &&
+           b->n_ranks >= 1 && b->n_ranks <= 4096 && b->rank < b->n_ranks;
+}
+// frame row of local row k (bands == NULL: a contiguous strip starting at y_offset)
+uint64_t frame_row(const mil_band_layout *b, uint32_t y_offset, uint32_t k)
+{
+    if (!b) return (uint64_t)y_offset + k;
+    return ((uint64_t)(k / b->band_rows) * b->n_ranks + b->rank) * b->band_rows + k % b->band_rows;
 }
 
-int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push)
+int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push, const mil_band_layout *bands)
 {
     if (!gb || !push) return MIL_ERR_BAD_ARG;
     if (!gb->normal_l_model || !gb->albedo_occlusion || !gb->roughness_metallic || !gb->depth) return MIL_ERR_BAD_ARG;
@@ -110,105 +89,118 @@ int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push)
     if ((uint64_t)gb->pitch_px * gb->height >= (1ull << 30)) return MIL_ERR_BAD_ARG;   // the kernels use 32-bit texel offsets (1 Gpx per plane)
     if (!(push->resolution[0] >= 1.0f) || !(push->resolution[1] >= 1.0f)) return MIL_ERR_BAD_ARG;
     if ((float)gb->width > push->resolution[0]) return MIL_ERR_BAD_ARG;
-    if ((double)gb->y_offset + (double)gb->height > (double)push->resolution[1]) return MIL_ERR_BAD_ARG;
+    if (bands && (!bands_ok(bands) || gb->y_offset != 0)) return MIL_ERR_BAD_ARG;
+    if ((double)frame_row(bands, gb->y_offset, gb->height - 1) + 1.0 > (double)push->resolution[1]) return MIL_ERR_BAD_ARG;
     return MIL_OK;
 }
 
-// Stage the light arrays and fill the light part of ShadeParams.
-// Layout per slot: dir_raw | dir_prep | point_raw | point_prep (n x 32 bytes each) | point_cull (n x 16).
-// The content is built on the host first; when it equals what the current slot already holds
-// (static lights, the common case frame to frame) nothing is uploaded.  Otherwise the next ring
-// slot is filled and uploaded on the context's copy stream, so the upload overlaps whatever the
-// caller's stream is still running, and the caller's stream waits on the slot's `staged` event.
+void slot_pointers(mil::ShadeParams &p, const uint8_t *dev, uint32_t capacity)
+{
+    const size_t dir_b = (size_t)MIL_MAX_DIR_LIGHTS * 32, pt_b = (size_t)capacity * 32;
+    p.dir_raw = (const float4 *)dev;
+    p.dir_prep = (const float4 *)(dev + dir_b);
+    p.point_raw = (const float4 *)(dev + 2 * dir_b);
+    p.point_prep = (const float4 *)(dev + 2 * dir_b + pt_b);
+    p.point_cull = (const float4 *)(dev + 2 * dir_b + 2 * pt_b);
+}
+
+// the first MIL_DIR_INLINE directional records travel in the kernarg, in the launch's mode layout
+void inline_dir_records(mil::ShadeParams &p, const mil_directional_light *dl, uint32_t n_dir, bool strict)
+{
+    for (uint32_t i = 0; i < n_dir && i < MIL_DIR_INLINE; i++) {
+        const mil_directional_light &l = dl[i];
+        float *q = p.dir_inline[i];
+        q[0] = l.direction[0]; q[1] = l.direction[1]; q[2] = l.direction[2];
+        if (strict) {
+            q[3] = l.intensity; q[4] = l.color[0]; q[5] = l.color[1]; q[6] = l.color[2];
+        } else {
+            q[3] = 0.0f; q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity;
+        }
+        q[7] = 0.0f;
+    }
+}
+
+// does the slot hold exactly these light arrays?  (raw copies; the prepared arrays derive from them)
+bool slot_holds(const mil_ctx *c, const Slot &sl, const mil_directional_light *dl, uint32_t n_dir, const mil_point_light *pl, uint32_t n_point)
+{
+    if (!sl.valid || sl.n_dir != n_dir || sl.n_point != n_point) return false;
+    const size_t dir_b = (size_t)MIL_MAX_DIR_LIGHTS * 32;
+    if (n_point && memcmp(sl.host + 2 * dir_b, pl, (size_t)n_point * 32)) return false;
+    for (uint32_t i = 0; i < n_dir; i++)
+        if (memcmp(sl.host + 32 * i, &dl[i], 28)) return false;      // the pad word is not part of the light
+    return true;
+}
+
+int slot_wait_readers(mil_ctx *c, Slot &sl)
+{
+    for (int i = 0; i < SLOT_STREAMS; i++)
+        if (sl.done_used[i]) {
+            HIP_TRY(c, hipEventSynchronize(sl.done[i]));
+            sl.done_used[i] = false;
+        }
+    return MIL_OK;
+}
+
+// Stage the light arrays and fill the light part of ShadeParams.  Static lights (the common case frame to frame) are
+// recognised by comparing the inputs with the raw copies the ring slots hold - the current slot first, then the others,
+// so a call with other content in between (mil_count_pairs, mil_transparency_accumulate) does not evict the frame's
+// lights - and then nothing is rebuilt or uploaded.  Otherwise the next ring slot is filled and uploaded on the
+// context's copy stream, so the upload overlaps whatever the caller's stream is still running, and the caller's stream
+// waits on the slot's `staged` event.
 int stage_lights(mil_ctx *c, const mil_directional_light *dl, uint32_t n_dir, const mil_point_light *pl,
                  uint32_t n_point, bool strict, hipStream_t s, mil::ShadeParams &p, Slot *&slot_out)
 {
     const size_t dir_b = (size_t)MIL_MAX_DIR_LIGHTS * 32, pt_b = (size_t)c->max_point * 32;
-    // Static lights (the common case frame to frame): the inputs equal the raw copies the current slot holds - the
-    // prepared arrays derive from those, so nothing is rebuilt, compared or uploaded (one memcmp of 32 bytes per light).
-    if (c->cur >= 0 && (n_dir > MIL_DIR_INLINE || n_point > 0)) {
-        Slot &cs = c->ring[c->cur];
-        bool same = cs.n_dir == n_dir && cs.n_point == n_point && (!n_point || !memcmp(cs.host + 2 * dir_b, pl, (size_t)n_point * 32));
-        for (uint32_t i = 0; same && i < n_dir; i++) same = !memcmp(cs.host + 32 * i, &dl[i], 28);      // the pad word is not part of the light
-        if (same) {
-            for (uint32_t i = 0; i < n_dir && i < MIL_DIR_INLINE; i++)
-                memcpy(p.dir_inline[i], cs.host + (strict ? 0 : dir_b) + 32 * i, 32);
-            HIP_TRY(c, hipStreamWaitEvent(s, cs.staged, 0));
-            p.dir_raw = (const float4 *)cs.dev;
-            p.dir_prep = (const float4 *)(cs.dev + dir_b);
-            p.point_raw = (const float4 *)(cs.dev + 2 * dir_b);
-            p.point_prep = (const float4 *)(cs.dev + 2 * dir_b + pt_b);
-            p.point_cull = (const float4 *)(cs.dev + 2 * dir_b + 2 * pt_b);
-            p.n_dir = n_dir; p.n_point = n_point;
-            slot_out = &cs;
-            return MIL_OK;
-        }
-    }
-    uint8_t *h = c->scratch;
-    float *h_dir_raw = (float *)h, *h_dir_prep = (float *)(h + dir_b);
-    float *h_pt_raw = (float *)(h + 2 * dir_b), *h_pt_prep = (float *)(h + 2 * dir_b + pt_b);
-    float *h_pt_cull = (float *)(h + 2 * dir_b + 2 * pt_b);
-    for (uint32_t i = 0; i < n_dir; i++) {
-        const mil_directional_light &l = dl[i];
-        float *r = h_dir_raw + 8 * i, *q = h_dir_prep + 8 * i;
-        r[0] = l.direction[0]; r[1] = l.direction[1]; r[2] = l.direction[2]; r[3] = l.intensity;
-        r[4] = l.color[0]; r[5] = l.color[1]; r[6] = l.color[2]; r[7] = 0.0f;
-        q[0] = l.direction[0]; q[1] = l.direction[1]; q[2] = l.direction[2]; q[3] = 0.0f;
-        q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity; q[7] = 0.0f;
-    }
-    for (uint32_t i = 0; i < n_point; i++) {
-        const mil_point_light &l = pl[i];
-        float *r = h_pt_raw + 8 * i, *q = h_pt_prep + 8 * i;
-        memcpy(r, &l, 32);
-        const float r2 = l.radius * l.radius;
-        q[0] = l.position[0]; q[1] = l.position[1]; q[2] = l.position[2]; q[3] = r2;
-        q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity;
-        q[7] = 1.0f / r2;
-        float *k = h_pt_cull + 4 * i;
-        k[0] = l.position[0]; k[1] = l.position[1]; k[2] = l.position[2]; k[3] = l.radius;
-    }
-    for (uint32_t i = 0; i < n_dir && i < MIL_DIR_INLINE; i++)
-        memcpy(p.dir_inline[i], (strict ? h_dir_raw : h_dir_prep) + 8 * i, 32);
-
-    // the first MIL_DIR_INLINE directional records travel in the kernarg; a device copy is needed
-    // only beyond that, or for point lights
-    const bool need_dev = n_dir > MIL_DIR_INLINE || n_point > 0;
-    Slot *sl = nullptr;
-    if (need_dev) {
-        const size_t nd = (size_t)n_dir * 32, np = (size_t)n_point * 32;
-        if (c->cur >= 0) {
-            Slot &cs = c->ring[c->cur];
-            if (cs.n_dir == n_dir && cs.n_point == n_point && !memcmp(cs.host, h, nd) && !memcmp(cs.host + dir_b, h + dir_b, nd) &&
-                !memcmp(cs.host + 2 * dir_b, h + 2 * dir_b, np) && !memcmp(cs.host + 2 * dir_b + pt_b, h + 2 * dir_b + pt_b, np) &&
-                !memcmp(cs.host + 2 * dir_b + 2 * pt_b, h + 2 * dir_b + 2 * pt_b, np / 2))
-                sl = &cs;
-        }
-        if (!sl) {
-            c->cur = c->next;
-            sl = &c->ring[c->next];
-            c->next = (c->next + 1) % RING;
-            if (sl->used) HIP_TRY(c, hipEventSynchronize(sl->done)); // kernels of RING contents ago may still read it
-            if (nd) { memcpy(sl->host, h, nd); memcpy(sl->host + dir_b, h + dir_b, nd); }
-            if (np) {
-                memcpy(sl->host + 2 * dir_b, h + 2 * dir_b, np);
-                memcpy(sl->host + 2 * dir_b + pt_b, h + 2 * dir_b + pt_b, np);
-                memcpy(sl->host + 2 * dir_b + 2 * pt_b, h + 2 * dir_b + 2 * pt_b, np / 2);
-            }
-            sl->n_dir = n_dir; sl->n_point = n_point;
-            sl->gen = ++c->gen;
-            if (nd) HIP_TRY(c, hipMemcpyAsync(sl->dev, sl->host, dir_b + nd, hipMemcpyHostToDevice, c->copy_stream));
-            if (np) HIP_TRY(c, hipMemcpyAsync(sl->dev + 2 * dir_b, sl->host + 2 * dir_b, 2 * pt_b + np / 2, hipMemcpyHostToDevice, c->copy_stream));
-            HIP_TRY(c, hipEventRecord(sl->staged, c->copy_stream));
-        }
-        HIP_TRY(c, hipStreamWaitEvent(s, sl->staged, 0));
-        p.dir_raw = (const float4 *)sl->dev;
-        p.dir_prep = (const float4 *)(sl->dev + dir_b);
-        p.point_raw = (const float4 *)(sl->dev + 2 * dir_b);
-        p.point_prep = (const float4 *)(sl->dev + 2 * dir_b + pt_b);
-        p.point_cull = (const float4 *)(sl->dev + 2 * dir_b + 2 * pt_b);
-    }
+    inline_dir_records(p, dl, n_dir, strict);
     p.n_dir = n_dir;
     p.n_point = n_point;
+    slot_out = nullptr;
+    // a device copy is needed only beyond the inline records, or for point lights
+    if (n_dir <= MIL_DIR_INLINE && n_point == 0) return MIL_OK;
+    Slot *sl = nullptr;
+    if (c->cur >= 0 && slot_holds(c, c->ring[c->cur], dl, n_dir, pl, n_point)) sl = &c->ring[c->cur];
+    for (int i = 0; !sl && i < RING; i++)
+        if (i != c->cur && slot_holds(c, c->ring[i], dl, n_dir, pl, n_point)) { sl = &c->ring[i]; c->cur = i; }
+    if (!sl) {
+        if (c->next == c->cur) c->next = (c->next + 1) % RING;      // keep the slot in use; take the one after it
+        sl = &c->ring[c->next];
+        int rc = slot_wait_readers(c, *sl);                         // kernels of RING contents ago may still read it
+        if (rc) return rc;
+        sl->valid = false;
+        float *h_dir_raw = (float *)sl->host, *h_dir_prep = (float *)(sl->host + dir_b);
+        float *h_pt_raw = (float *)(sl->host + 2 * dir_b), *h_pt_prep = (float *)(sl->host + 2 * dir_b + pt_b);
+        float *h_pt_cull = (float *)(sl->host + 2 * dir_b + 2 * pt_b);
+        for (uint32_t i = 0; i < n_dir; i++) {
+            const mil_directional_light &l = dl[i];
+            float *r = h_dir_raw + 8 * i, *q = h_dir_prep + 8 * i;
+            r[0] = l.direction[0]; r[1] = l.direction[1]; r[2] = l.direction[2]; r[3] = l.intensity;
+            r[4] = l.color[0]; r[5] = l.color[1]; r[6] = l.color[2]; r[7] = 0.0f;
+            q[0] = l.direction[0]; q[1] = l.direction[1]; q[2] = l.direction[2]; q[3] = 0.0f;
+            q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity; q[7] = 0.0f;
+        }
+        for (uint32_t i = 0; i < n_point; i++) {
+            const mil_point_light &l = pl[i];
+            float *r = h_pt_raw + 8 * i, *q = h_pt_prep + 8 * i;
+            memcpy(r, &l, 32);
+            const float r2 = l.radius * l.radius;
+            q[0] = l.position[0]; q[1] = l.position[1]; q[2] = l.position[2]; q[3] = r2;
+            q[4] = l.color[0] * l.intensity; q[5] = l.color[1] * l.intensity; q[6] = l.color[2] * l.intensity;
+            q[7] = 1.0f / r2;
+            float *k = h_pt_cull + 4 * i;
+            k[0] = l.position[0]; k[1] = l.position[1]; k[2] = l.position[2]; k[3] = l.radius;
+        }
+        const size_t nd = (size_t)n_dir * 32, np = (size_t)n_point * 32;
+        if (nd) HIP_TRY(c, hipMemcpyAsync(sl->dev, sl->host, dir_b + nd, hipMemcpyHostToDevice, c->copy_stream));
+        if (np) HIP_TRY(c, hipMemcpyAsync(sl->dev + 2 * dir_b, sl->host + 2 * dir_b, 2 * pt_b + np / 2, hipMemcpyHostToDevice, c->copy_stream));
+        HIP_TRY(c, hipEventRecord(sl->staged, c->copy_stream));
+        sl->n_dir = n_dir; sl->n_point = n_point;
+        sl->gen = ++c->gen;
+        sl->valid = true;
+        c->cur = c->next;
+        c->next = (c->next + 1) % RING;
+    }
+    HIP_TRY(c, hipStreamWaitEvent(s, sl->staged, 0));
+    slot_pointers(p, sl->dev, c->max_point);
     slot_out = sl;
     return MIL_OK;
 }
@@ -237,11 +229,19 @@ void fold_position_matrix(const mil_frame_matrix_data *f, float res_x, float res
         for (int c = 0; c < 4; c++) out16[r * 4 + c] = (float)A[r][c];
 }
 
-void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_matrix_data *f, const mil_push_constants *push)
+void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_matrix_data *f, const mil_push_constants *push,
+                 const mil_band_layout *bands)
 {
     memset(&p, 0, sizeof(p));
     p.normal = gb->normal_l_model; p.albedo = gb->albedo_occlusion; p.rm = gb->roughness_metallic; p.depth = gb->depth;
     p.width = gb->width; p.height = gb->height; p.pitch = gb->pitch_px; p.y_offset = gb->y_offset;
+    if (bands && bands->n_ranks > 1) {      // one rank: the dealing is the identity
+        uint32_t sh = 0;
+        while ((1u << sh) < bands->band_rows) sh++;
+        p.band_shift = sh;
+        p.band_extra = (bands->n_ranks - 1u) * bands->band_rows;
+        p.y_offset = bands->rank * bands->band_rows;
+    }
     memcpy(p.inv_proj, f->inv_projection, 64);
     memcpy(p.inv_view, f->inv_view, 64);
     memcpy(p.cam, f->camera_position, 12);
@@ -254,47 +254,77 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
     for (uint32_t i = 0; i < MIL_MAX_ROW_ORDER; i++) p.row_order[i] = (uint16_t)i;
 }
 
+// Scheduling weight of the local tile rows of a launch: w[i] = number of point lights whose bounding sphere can project
+// onto local tile row i.  Lights behind the camera weigh nothing; a sphere the near plane cuts counts for every row.
+void row_weights(const mil_frame_matrix_data *f, float res_y, uint32_t height, uint32_t y_offset, const mil_band_layout *bands,
+                 const mil_point_light *pl, uint32_t n_point, uint32_t *w)
+{
+    const uint32_t R = (height + MIL_TILE - 1) / MIL_TILE;
+    for (uint32_t i = 0; i < R; i++) w[i] = 0;
+    if (bands && bands->n_ranks <= 1) bands = nullptr;
+    const float *V = f->view, *P = f->projection;      // column-major
+    const uint32_t tpb = bands ? bands->band_rows / MIL_TILE : 1;   // tile rows per band
+    for (uint32_t i = 0; i < n_point; i++) {
+        const float *c = pl[i].position;
+        const double r = pl[i].radius;
+        if (!(r > 0.0)) continue;                       // radius 0 (or NaN): reaches no pixel
+        const double vy = (double)V[1] * c[0] + (double)V[5] * c[1] + (double)V[9] * c[2] + V[13];
+        const double vz = (double)V[2] * c[0] + (double)V[6] * c[1] + (double)V[10] * c[2] + V[14];
+        const double vw = (double)V[3] * c[0] + (double)V[7] * c[1] + (double)V[11] * c[2] + V[15];
+        double lo = -1.0, hi = 1.0;                     // NDC y range; whole frame unless the sphere is safely in front
+        if (P[11] != 0.0f) {
+            // clip w = P[11] z + P[15] w at the sphere's near / far side (P[11] = -1 for a perspective, view z < 0 in front)
+            const double wn = (double)P[11] * (vz + r) + (double)P[15] * vw, wf = (double)P[11] * (vz - r) + (double)P[15] * vw;
+            if (wn <= 0.0 && wf <= 0.0) continue;       // wholly behind the camera
+            if (wn > 1e-6 && wf > 1e-6) {
+                const double a = (double)P[5] * (vy - r) + (double)P[13] * vw, b = (double)P[5] * (vy + r) + (double)P[13] * vw;
+                const double c0 = a / wn, c1 = a / wf, c2 = b / wn, c3 = b / wf;
+                lo = c0; hi = c0;
+                for (double v : { c1, c2, c3 }) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+            }
+        }
+        if (!(lo == lo) || !(hi == hi)) { lo = -1.0; hi = 1.0; }
+        const double y0 = (lo * 0.5 + 0.5) * res_y, y1 = (hi * 0.5 + 0.5) * res_y;      // frame rows
+        if (y1 < 0.0 || y0 >= (double)res_y) continue;
+        const uint64_t g0 = y0 <= 0.0 ? 0u : (uint64_t)(y0 / MIL_TILE), g1 = (uint64_t)((y1 >= (double)res_y ? (double)res_y - 1.0 : y1) / MIL_TILE);
+        if (!bands) {                                   // local tile row = frame tile row - y_offset / 16 (strips start on any row)
+            const double l0 = y0 - (double)y_offset, l1 = y1 - (double)y_offset;
+            if (l1 < 0.0 || l0 >= (double)height) continue;
+            const uint32_t r0 = l0 <= 0.0 ? 0u : (uint32_t)(l0 / MIL_TILE), r1 = l1 >= (double)height ? R - 1 : (uint32_t)(l1 / MIL_TILE);
+            for (uint32_t k = r0; k <= r1 && k < R; k++) w[k]++;
+        } else {
+            for (uint64_t g = g0; g <= g1; g++) {       // frame tile row g lies in band g / tpb
+                const uint64_t band = g / tpb;
+                if (band % bands->n_ranks != bands->rank) continue;
+                const uint64_t k = (band / bands->n_ranks) * tpb + g % tpb;
+                if (k < R) w[k]++;
+            }
+        }
+    }
+}
+
 // Scheduling heuristic of the tiled kernel (speed only; any permutation is correct): tile rows are launched
 // in descending order of the number of point lights whose bounding sphere can project onto them, ties from the
 // bottom of the frame upwards, so that the expensive rows are in flight early and the launch ends on cheap ones.
-struct RowOrderKey { float view[16], proj[16]; uint32_t height, y_offset, n_point; float res_y; uint64_t lights_gen; };
-void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_point_light *pl, uint32_t n_point)
+struct RowOrderKey { float view[16], proj[16]; uint32_t height, y_offset, n_point, band_rows, n_ranks, rank; float res_y; uint64_t lights_gen; };
+void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_band_layout *bands,
+                uint32_t gb_y_offset, const mil_point_light *pl, uint32_t n_point)
 {
     const uint32_t R = p.tiles_y;
-    if (R > MIL_MAX_ROW_ORDER) return;
+    if (R > MIL_MAX_ROW_ORDER || !pl) return;
     // same lights (slot generation), camera and strip as the last call: same order
     RowOrderKey key;
     memset(&key, 0, sizeof(key));
     memcpy(key.view, f->view, 64); memcpy(key.proj, f->projection, 64);
-    key.height = p.height; key.y_offset = p.y_offset; key.n_point = n_point; key.res_y = p.res_y; key.lights_gen = lights ? lights->gen : 0;
+    key.height = p.height; key.y_offset = gb_y_offset; key.n_point = n_point; key.res_y = p.res_y; key.lights_gen = lights ? lights->gen : 0;
+    if (bands) { key.band_rows = bands->band_rows; key.n_ranks = bands->n_ranks; key.rank = bands->rank; }
     static_assert(sizeof(c->row_key) >= sizeof(RowOrderKey), "row order key storage");
     if (c->row_key_valid && !memcmp(c->row_key, &key, sizeof(key))) {
         memcpy(p.row_order, c->row_order, sizeof(p.row_order));
         return;
     }
     uint32_t w[MIL_MAX_ROW_ORDER];
-    for (uint32_t i = 0; i < R; i++) w[i] = 0;
-    const float *V = f->view, *P = f->projection;      // column-major
-    for (uint32_t i = 0; i < n_point; i++) {
-        const float *c = pl[i].position;
-        const float r = pl[i].radius;
-        const double vy = (double)V[1] * c[0] + (double)V[5] * c[1] + (double)V[9] * c[2] + V[13];
-        const double vz = (double)V[2] * c[0] + (double)V[6] * c[1] + (double)V[10] * c[2] + V[14];
-        const double vw = (double)V[3] * c[0] + (double)V[7] * c[1] + (double)V[11] * c[2] + V[15];
-        double lo = -1.0, hi = 1.0;                     // NDC y range; whole frame unless the sphere is safely in front
-        const double wn = -(vz + r) * (double)P[11] + vw * P[15], wf = -(vz - r) * (double)P[11] + vw * P[15];   // clip w at the sphere's near / far side (P[11] = -1 for a perspective)
-        if (P[11] != 0.0f && wn > 1e-6 && wf > 1e-6 && !(r < 0.0f)) {
-            const double a = (double)P[5] * (vy - r) + (double)P[13] * vw, b = (double)P[5] * (vy + r) + (double)P[13] * vw;
-            const double c0 = a / wn, c1 = a / wf, c2 = b / wn, c3 = b / wf;
-            lo = c0; hi = c0;
-            for (double v : { c1, c2, c3 }) { lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
-        }
-        if (!(lo == lo) || !(hi == hi)) { lo = -1.0; hi = 1.0; }
-        double y0 = (lo * 0.5 + 0.5) * p.res_y - (double)p.y_offset, y1 = (hi * 0.5 + 0.5) * p.res_y - (double)p.y_offset;
-        if (y1 < 0.0 || y0 >= (double)p.height) continue;
-        const uint32_t r0 = y0 <= 0.0 ? 0u : (uint32_t)(y0 / MIL_TILE), r1 = y1 >= (double)p.height ? R - 1 : (uint32_t)(y1 / MIL_TILE);
-        for (uint32_t k = r0; k <= r1 && k < R; k++) w[k]++;
-    }
+    row_weights(f, p.res_y, p.height, gb_y_offset, bands, pl, n_point, w);
     // stable counting order: weight descending, then row index descending (bottom first)
     uint32_t n = 0;
     uint32_t wmax = 0;
@@ -307,13 +337,27 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     c->row_key_valid = true;
 }
 
-int finish(mil_ctx *c, Slot *sl, hipStream_t s)
+// A launch was issued (status `launch`); remember on which stream the slot's content is being read.
+int finish(mil_ctx *c, Slot *sl, hipStream_t s, hipError_t launch)
 {
-    HIP_TRY(c, hipGetLastError());
-    if (sl) {
-        HIP_TRY(c, hipEventRecord(sl->done, s));
-        sl->used = true;
+    if (launch != hipSuccess) return hip_fail(c, launch);
+    if (!sl) return MIL_OK;
+    int k = -1;
+    for (int i = 0; i < SLOT_STREAMS && k < 0; i++)
+        if (sl->done_used[i] && sl->done_stream[i] == s) k = i;
+    for (int i = 0; i < SLOT_STREAMS && k < 0; i++)
+        if (!sl->done_used[i]) k = i;
+    if (k < 0) {        // four other streams are tracked: retire an entry whose kernel has finished, else wait for the oldest
+        for (int i = 0; i < SLOT_STREAMS && k < 0; i++)
+            if (hipEventQuery(sl->done[i]) == hipSuccess) k = i;
+        if (k < 0) {
+            HIP_TRY(c, hipEventSynchronize(sl->done[0]));
+            k = 0;
+        }
     }
+    HIP_TRY(c, hipEventRecord(sl->done[k], s));
+    sl->done_stream[k] = s;
+    sl->done_used[k] = true;
     return MIL_OK;
 }
 
@@ -332,6 +376,7 @@ const char *mil_strerror(int st)
     case MIL_ERR_HIP: return "HIP runtime error (see mil_last_hip_error)";
     case MIL_ERR_NO_DEVICE: return "no such HIP device";
     case MIL_ERR_CAPACITY: return "more point lights than the context capacity";
+    case MIL_ERR_RCCL: return "RCCL error or librccl missing (see mil_mg_last_rccl_error)";
     default: return "unknown status";
     }
 }
@@ -349,24 +394,27 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
     if (!c) return MIL_ERR_HIP;
     c->device = device;
     c->max_point = max_point_lights;
-    if (const char *e = getenv("MIL_TUNE")) c->tune = (uint32_t)atoi(e);
-    if (const char *e = getenv("MIL_TONEMAP_ROWS")) c->tonemap_rows = (uint32_t)atoi(e);
-    if (const char *e = getenv("MIL_FXAA_ROWS")) c->fxaa_rows = atoi(e) == 4 ? 4u : 2u;
-    if (const char *e = getenv("MIL_K1_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->k1_rows = (uint32_t)v; }
+    // Tuning knobs select kernels and paths the parity suite does not cover in every combination: a stray variable in the
+    // host renderer's environment must not switch them, so they are read only under MIL_DEBUG=1.
+    const char *dbg = getenv("MIL_DEBUG");
+    if (dbg && atoi(dbg) == 1) {
+        if (const char *e = getenv("MIL_TUNE")) c->tune = (uint32_t)atoi(e);
+        if (const char *e = getenv("MIL_TONEMAP_ROWS")) c->tonemap_rows = (uint32_t)atoi(e);
+        if (const char *e = getenv("MIL_FXAA_ROWS")) c->fxaa_rows = atoi(e) == 4 ? 4u : 2u;
+        if (const char *e = getenv("MIL_K1_ROWS")) { int v = atoi(e); if (v >= 1 && v <= 64) c->k1_rows = (uint32_t)v; }
+    }
     c->slot_bytes = 2 * (size_t)MIL_MAX_DIR_LIGHTS * 32 + (size_t)max_point_lights * (32 + 32 + 16);
     int rc = set_device(c);
     for (int i = 0; rc == MIL_OK && i < RING; i++) {
         Slot &s = c->ring[i];
         if (hipHostMalloc((void **)&s.host, c->slot_bytes, hipHostMallocDefault) != hipSuccess ||
             hipMalloc((void **)&s.dev, c->slot_bytes) != hipSuccess ||
-            hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.staged, hipEventDisableTiming) != hipSuccess)
             rc = MIL_ERR_HIP;
+        for (int k = 0; rc == MIL_OK && k < SLOT_STREAMS; k++)
+            if (hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming) != hipSuccess) rc = MIL_ERR_HIP;
     }
-    if (rc == MIL_OK) {
-        c->scratch = (uint8_t *)malloc(c->slot_bytes);
-        if (!c->scratch || hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MIL_ERR_HIP;
-    }
+    if (rc == MIL_OK && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MIL_ERR_HIP;
     if (rc == MIL_OK) {
         uint8_t h[LUT11_N + LUT10_N];
         for (uint32_t i = 0; i < LUT11_N; i++) h[i] = srgb8(ufloat_dec(i, 6));
@@ -387,31 +435,55 @@ void mil_destroy(mil_ctx *c)
 {
     if (!c) return;
     set_device(c);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     for (Slot &s : c->ring) {
-        if (s.used) (void)hipEventSynchronize(s.done);
-        if (s.done) (void)hipEventDestroy(s.done);
+        (void)slot_wait_readers(c, s);
+        for (int k = 0; k < SLOT_STREAMS; k++)
+            if (s.done[k]) (void)hipEventDestroy(s.done[k]);
         if (s.staged) (void)hipEventDestroy(s.staged);
         if (s.host) (void)hipHostFree(s.host);
         if (s.dev) (void)hipFree(s.dev);
     }
     if (c->lut) (void)hipFree(c->lut);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    free(c->scratch);
     delete c;
 }
 
-int mil_set_tile_count_buffer(mil_ctx *c, uint32_t *counts)
+int mil_set_tile_count_buffer(mil_ctx *c, uint32_t *counts, uint32_t n_tiles)
 {
     if (!c) return MIL_ERR_BAD_ARG;
     c->tile_counts = counts;
+    c->tile_counts_cap = counts ? n_tiles : 0;
     return MIL_OK;
 }
 
-int mil_set_tile_stamp_buffer(mil_ctx *c, uint32_t *stamps)
+int mil_set_tile_stamp_buffer(mil_ctx *c, uint32_t *stamps, uint32_t n_tiles)
 {
     if (!c) return MIL_ERR_BAD_ARG;
     c->tile_stamps = stamps;
+    c->tile_stamps_cap = stamps ? n_tiles : 0;
     return MIL_OK;
+}
+
+int mil_row_weights(const mil_frame_matrix_data *frame, const mil_push_constants *push, uint32_t gb_height, uint32_t y_offset,
+                    const mil_band_layout *bands, const mil_point_light *pl, uint32_t n_point, uint32_t *weights)
+{
+    if (!frame || !push || !weights || gb_height == 0 || (n_point && !pl)) return MIL_ERR_BAD_ARG;
+    if (bands && (!bands_ok(bands) || y_offset != 0)) return MIL_ERR_BAD_ARG;
+    if (!(push->resolution[1] >= 1.0f)) return MIL_ERR_BAD_ARG;
+    row_weights(frame, push->resolution[1], gb_height, y_offset, bands, pl, n_point, weights);
+    return MIL_OK;
+}
+
+uint32_t mil_band_local_rows(const mil_band_layout *b, uint32_t height)
+{
+    if (!b || !bands_ok(b)) return 0;
+    const uint64_t nb = ((uint64_t)height + b->band_rows - 1) / b->band_rows;        // bands of the frame, the last may be short
+    if (b->rank >= nb) return 0;
+    const uint64_t mine = (nb - b->rank + b->n_ranks - 1) / b->n_ranks;              // bands rank, rank + n, ...
+    uint64_t rows = mine * b->band_rows;
+    if ((nb - 1) % b->n_ranks == b->rank) rows -= nb * b->band_rows - height;       // the short last band is this rank's
+    return (uint32_t)rows;
 }
 
 int mil_sync(mil_ctx *c, void *stream)
@@ -423,32 +495,46 @@ int mil_sync(mil_ctx *c, void *stream)
     return MIL_OK;
 }
 
-// mil_light_ex and mil_shade_frame: the same launch, the second with the later subpasses folded into the store
-static int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
-                 const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
-                 const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
+} // extern "C"
+
+// mil_light_ex, mil_shade_frame, mil_shade_bands: the same launch, the later ones with the later subpasses folded into the
+// store / the rows dealt in bands.  Every argument is validated before anything is staged or enqueued: an argument error
+// has no side effect.
+int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                   const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                   const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream,
+                   const mil_band_layout *bands, bool out_frame, const PreStaged *pre)
 {
     if (!c || !frame || !out) return MIL_ERR_BAD_ARG;
     if (passes && ((passes->accum != nullptr) != (passes->reveal != nullptr))) return MIL_ERR_BAD_ARG;
-    int rc = check_gbuffer(gb, push);
+    int rc = check_gbuffer(gb, push, bands);
     if (rc) return rc;
     if (out_pitch_px < gb->width || (unsigned)fmt > MIL_OUT_SRGB8_BGRA_VIA_LDR) return MIL_ERR_BAD_ARG;
     if (push->light_count > MIL_MAX_DIR_LIGHTS) return MIL_ERR_TOO_MANY_LIGHTS;
     if (push->light_count && !lights) return MIL_ERR_BAD_ARG;
     const uint32_t n_point = ex ? ex->n_point : 0;
-    if (n_point > c->max_point) return MIL_ERR_CAPACITY;
+    if (n_point > (pre ? pre->capacity : c->max_point)) return MIL_ERR_CAPACITY;
     if (n_point && !ex->point_lights) return MIL_ERR_BAD_ARG;
     const mil_shadow *sh = ex ? ex->shadow : nullptr;
     if (sh && (!sh->map || sh->size == 0 || sh->size > 16384u)) return MIL_ERR_BAD_ARG;   // 32-bit texel offsets in the taps
+    if (passes && passes->accum && (passes->accum_pitch_px < gb->width || passes->reveal_pitch_px < gb->width)) return MIL_ERR_BAD_ARG;
+    if (out_frame && !bands) return MIL_ERR_BAD_ARG;
     if ((rc = set_device(c))) return rc;
 
     hipStream_t s = (hipStream_t)stream;
+    const bool strict = (flags & MIL_FLAG_STRICT) != 0;
     mil::ShadeParams p;
-    fill_common(p, gb, frame, push);
+    fill_common(p, gb, frame, push, bands);
     p.rows_per_block = c->k1_rows;
     p.tune = c->tune;
     Slot *slot = nullptr;
-    if ((rc = stage_lights(c, lights, push->light_count, ex ? ex->point_lights : nullptr, n_point, (flags & MIL_FLAG_STRICT) != 0, s, p, slot))) return rc;
+    if (pre) {          // the light arrays are on the device already (prepared by a kernel earlier on this stream)
+        inline_dir_records(p, lights, push->light_count, strict);
+        p.n_dir = push->light_count; p.n_point = n_point;
+        slot_pointers(p, pre->dev, pre->capacity);
+    } else if ((rc = stage_lights(c, lights, push->light_count, ex ? ex->point_lights : nullptr, n_point, strict, s, p, slot))) {
+        return rc;
+    }
     if (ex && (ex->ambient[0] != 0.0f || ex->ambient[1] != 0.0f || ex->ambient[2] != 0.0f)) {
         p.has_ambient = 1;
         memcpy(p.ambient, ex->ambient, 12);
@@ -463,11 +549,14 @@ static int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
     }
     p.out = out;
     p.out_pitch = out_pitch_px;
+    if (out_frame) {    // rows of the assembled frame: the dealing's row map applies to the store too
+        p.out_band_extra = p.band_extra;
+        p.out = (uint8_t *)out + (size_t)p.y_offset * out_pitch_px * (fmt == MIL_OUT_HDR_RGBA32F ? 16u : 4u);
+    }
     p.lut11 = c->lut;
     p.lut10 = c->lut + LUT11_N;
     const bool whole = passes != nullptr;
     if (whole) {
-        if (passes->accum && (passes->accum_pitch_px < gb->width || passes->reveal_pitch_px < gb->width)) return MIL_ERR_BAD_ARG;
         if (passes->sky) {
             p.has_sky = 1;
             static_assert(sizeof(p.hw) == sizeof(mil_hosek_wilkie_params), "HosekWilkieParams is 11 x vec4");
@@ -478,35 +567,46 @@ static int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data 
         p.resolve_dma = p.accum && !(gb->width & 1u) && !(p.reveal_pitch & 1u) && !((uintptr_t)p.reveal & 3u) && !((uintptr_t)p.accum & 3u) && !(c->tune & 128u);
     }
 
-    const bool strict = (flags & MIL_FLAG_STRICT) != 0;
     const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
+    hipError_t le;
     if (tiled) {
-        order_rows(c, slot, p, frame, ex ? ex->point_lights : nullptr, n_point);
-        p.tile_counts = c->tile_counts;
-        p.tile_stamps = c->tile_stamps;
-        if (strict) mil::strict::launch_tiled((int)fmt, p, whole, s);
-        else mil::fast::launch_tiled((int)fmt, p, whole, s);
+        if (!pre) order_rows(c, slot, p, frame, bands, gb->y_offset, ex ? ex->point_lights : nullptr, n_point);
+        const uint32_t n_tiles = p.tiles_x * p.tiles_y;        // < 2^22: pitch * height < 2^30
+        p.tile_counts = n_tiles <= c->tile_counts_cap ? c->tile_counts : nullptr;
+        p.tile_stamps = n_tiles <= c->tile_stamps_cap ? c->tile_stamps : nullptr;
+        le = strict ? mil::strict::launch_tiled((int)fmt, p, whole, s) : mil::fast::launch_tiled((int)fmt, p, whole, s);
     } else {
-        if (strict) mil::strict::launch_stream((int)fmt, p, whole, s);
-        else mil::fast::launch_stream((int)fmt, p, whole, s);
+        le = strict ? mil::strict::launch_stream((int)fmt, p, whole, s) : mil::fast::launch_stream((int)fmt, p, whole, s);
     }
-    return finish(c, slot, s);
+    return finish(c, slot, s, le);
 }
+
+extern "C" {
 
 int mil_light_ex(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
                  const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
                  void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream)
 {
-    return shade(c, gb, frame, lights, push, ex, nullptr, out, out_pitch_px, fmt, flags, stream);
+    return shade(c, gb, frame, lights, push, ex, nullptr, out, out_pitch_px, fmt, flags, stream, nullptr, false, nullptr);
 }
+
+static const mil_frame_passes no_passes = {};
 
 int mil_shade_frame(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
                     const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
                     const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt,
                     uint32_t flags, void *stream)
 {
-    static const mil_frame_passes none = {};
-    return shade(c, gb, frame, lights, push, ex, passes ? passes : &none, out, out_pitch_px, fmt, flags, stream);
+    return shade(c, gb, frame, lights, push, ex, passes ? passes : &no_passes, out, out_pitch_px, fmt, flags, stream, nullptr, false, nullptr);
+}
+
+int mil_shade_bands(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                    const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                    const mil_frame_passes *passes, const mil_band_layout *bands, void *out, uint32_t out_pitch_px,
+                    int out_is_frame, mil_out_format fmt, uint32_t flags, void *stream)
+{
+    return shade(c, gb, frame, lights, push, ex, passes ? passes : &no_passes, out, out_pitch_px, fmt, flags, stream, bands,
+                 bands != nullptr && out_is_frame != 0, nullptr);
 }
 
 int mil_light_directional(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
@@ -530,9 +630,8 @@ int mil_tonemap(mil_ctx *c, const float *hdr, uint32_t hdr_pitch_px, uint32_t wi
     p.hdr_pitch = hdr_pitch_px; p.out_pitch = out_pitch_px;
     p.lut11 = c->lut; p.lut10 = c->lut + LUT11_N;
     p.rows = c->tonemap_rows;
-    if (flags & MIL_FLAG_STRICT) mil::strict::launch_tonemap((int)fmt, p, (hipStream_t)stream);
-    else mil::fast::launch_tonemap((int)fmt, p, (hipStream_t)stream);
-    return finish(c, nullptr, (hipStream_t)stream);
+    const hipError_t le = (flags & MIL_FLAG_STRICT) ? mil::strict::launch_tonemap((int)fmt, p, (hipStream_t)stream) : mil::fast::launch_tonemap((int)fmt, p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream, le);
 }
 
 int mil_fxaa(mil_ctx *c, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t width, uint32_t height, uint32_t row_begin,
@@ -549,9 +648,8 @@ int mil_fxaa(mil_ctx *c, const uint32_t *ldr, uint32_t ldr_pitch_px, uint32_t wi
     p.row_begin = row_begin; p.row_count = row_count;
     p.lut11 = c->lut; p.lut10 = c->lut + LUT11_N;
     p.rows = c->fxaa_rows;
-    if (flags & MIL_FLAG_STRICT) mil::strict::launch_fxaa(p, (hipStream_t)stream);
-    else mil::fast::launch_fxaa(p, (hipStream_t)stream);
-    return finish(c, nullptr, (hipStream_t)stream);
+    const hipError_t le = (flags & MIL_FLAG_STRICT) ? mil::strict::launch_fxaa(p, (hipStream_t)stream) : mil::fast::launch_fxaa(p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream, le);
 }
 
 int mil_sky_hosek(mil_ctx *c, const float *depth, uint32_t depth_pitch_px, uint32_t width, uint32_t height, uint32_t y_offset,
@@ -572,9 +670,8 @@ int mil_sky_hosek(mil_ctx *c, const float *depth, uint32_t depth_pitch_px, uint3
     p.res_x = push->resolution[0]; p.res_y = push->resolution[1];
     fold_position_matrix(frame, p.res_x, p.res_y, p.pos_m);
     memcpy(p.hw, params, sizeof(p.hw));
-    if (flags & MIL_FLAG_STRICT) mil::strict::launch_sky(p, (hipStream_t)stream);
-    else mil::fast::launch_sky(p, (hipStream_t)stream);
-    return finish(c, nullptr, (hipStream_t)stream);
+    const hipError_t le = (flags & MIL_FLAG_STRICT) ? mil::strict::launch_sky(p, (hipStream_t)stream) : mil::fast::launch_sky(p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream, le);
 }
 
 int mil_transparency_resolve(mil_ctx *c, const void *accum, uint32_t accum_pitch_px, const void *reveal, uint32_t reveal_pitch_px,
@@ -587,9 +684,8 @@ int mil_transparency_resolve(mil_ctx *c, const void *accum, uint32_t accum_pitch
     mil::ResolveParams p;
     p.accum = (const uint16_t *)accum; p.reveal = (const uint16_t *)reveal; p.hdr = hdr; p.width = width; p.height = height;
     p.accum_pitch = accum_pitch_px; p.reveal_pitch = reveal_pitch_px; p.hdr_pitch = hdr_pitch_px;
-    if (flags & MIL_FLAG_STRICT) mil::strict::launch_resolve(p, (hipStream_t)stream);
-    else mil::fast::launch_resolve(p, (hipStream_t)stream);
-    return finish(c, nullptr, (hipStream_t)stream);
+    const hipError_t le = (flags & MIL_FLAG_STRICT) ? mil::strict::launch_resolve(p, (hipStream_t)stream) : mil::fast::launch_resolve(p, (hipStream_t)stream);
+    return finish(c, nullptr, (hipStream_t)stream, le);
 }
 
 int mil_transparency_accumulate(mil_ctx *c, const mil_transparent_fragments *fr, const mil_frame_matrix_data *frame,
@@ -616,8 +712,10 @@ int mil_transparency_accumulate(mil_ctx *c, const mil_transparent_fragments *fr,
     // when it holds the same directional lights (the reference binds one lights UBO to both draws, render/mod.rs:252)
     Slot *slot = nullptr;
     if (p.n_dir > MIL_DIR_INLINE) {
-        if (c->cur >= 0 && c->ring[c->cur].n_dir == p.n_dir) {
-            Slot &cs = c->ring[c->cur];
+        const int base = c->cur < 0 ? 0 : c->cur;            // the frame's lighting call staged them most likely
+        for (int k = 0; !slot && k < RING; k++) {
+            Slot &cs = c->ring[(base + k) % RING];
+            if (!cs.valid || cs.n_dir != p.n_dir) continue;
             bool same = true;
             for (uint32_t i = 0; same && i < p.n_dir; i++) same = !memcmp(cs.host + 32 * i, &lights[i], 28);
             if (same) {
@@ -632,9 +730,8 @@ int mil_transparency_accumulate(mil_ctx *c, const mil_transparent_fragments *fr,
             p.dir_raw = sp.dir_raw;
         }
     }
-    if (flags & MIL_FLAG_STRICT) mil::strict::launch_accumulate(p, s);
-    else mil::fast::launch_accumulate(p, s);
-    return finish(c, slot, s);
+    const hipError_t le = (flags & MIL_FLAG_STRICT) ? mil::strict::launch_accumulate(p, s) : mil::fast::launch_accumulate(p, s);
+    return finish(c, slot, s, le);
 }
 
 int mil_import_external_memory(mil_ctx *c, int fd, uint64_t size, mil_external_memory **mem, void **dev_ptr)
@@ -722,19 +819,18 @@ int mil_count_pairs(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_da
                     const mil_point_light *pl, uint32_t n_point, unsigned long long *count, void *stream)
 {
     if (!c || !frame || !count) return MIL_ERR_BAD_ARG;
-    int rc = check_gbuffer(gb, push);
+    int rc = check_gbuffer(gb, push, nullptr);
     if (rc) return rc;
     if (n_point > c->max_point) return MIL_ERR_CAPACITY;
     if (n_point && !pl) return MIL_ERR_BAD_ARG;
     if ((rc = set_device(c))) return rc;
     hipStream_t s = (hipStream_t)stream;
     mil::ShadeParams p;
-    fill_common(p, gb, frame, push);
+    fill_common(p, gb, frame, push, nullptr);
     Slot *slot = nullptr;
     if ((rc = stage_lights(c, nullptr, 0, pl, n_point, false, s, p, slot))) return rc;
     HIP_TRY(c, hipMemsetAsync(count, 0, sizeof(unsigned long long), s));
-    mil::fast::launch_count_pairs(p, count, s);
-    return finish(c, slot, s);
+    return finish(c, slot, s, mil::fast::launch_count_pairs(p, count, s));
 }
 
 } // extern "C"

@@ -63,6 +63,17 @@ DEV DirRec dir_rec(const ShadeParams &p, uint32_t l)
     return d;
 }
 
+// Rows.  A kernel addresses its planes by LOCAL rows; PositionFromDepth needs the row of the whole frame
+// (fs_deferred_lighting.glsl:31: gl_FragCoord.y) and the output may be the assembled frame.  Both differ from the local row
+// by an offset that is uniform over any 16-row-aligned group of rows (mil_params.h, band dealing), so every wave computes
+// them once, on the scalar unit, from the first row it covers.
+struct RowMap { uint32_t g, o; };      // frame row = local + g; output row = local + o
+DEV RowMap row_map(const ShadeParams &p, uint32_t y_base)
+{
+    const uint32_t b = y_base >> p.band_shift;
+    return RowMap{ p.y_offset + b * p.band_extra, b * p.out_band_extra };
+}
+
 // ---------------------------------------------------------------------------------
 // per-pixel state
 // ---------------------------------------------------------------------------------
@@ -99,11 +110,11 @@ DEV float mrow(const float *m, int r, float x, float y, float z, float w)
     return ((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w;
 }
 
-// PositionFromDepth, fs_deferred_lighting.glsl:30-38 (y is the strip-local row)
+// PositionFromDepth, fs_deferred_lighting.glsl:30-38 (yg is the row of the whole frame)
 struct Pos { f3 P; };
-DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t yg, float depth)
 {
-    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
+    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)yg + 0.5f) / p.res_y;
     float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
     float vx = mrow(p.inv_proj, 0, px, py, depth, 1.0f), vy = mrow(p.inv_proj, 1, px, py, depth, 1.0f);
     float vz = mrow(p.inv_proj, 2, px, py, depth, 1.0f), vw = mrow(p.inv_proj, 3, px, py, depth, 1.0f);
@@ -306,9 +317,9 @@ template <typename T> DEV PosT<T> pixel_position_t(const ShadeParams &p, T xf, T
     return r;
 }
 typedef PosT<float> Pos;
-DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t y, float depth)
+DEV Pos pixel_position(const ShadeParams &p, uint32_t x, uint32_t yg, float depth)
 {
-    return pixel_position_t<float>(p, (float)x, (float)(y + p.y_offset), depth);
+    return pixel_position_t<float>(p, (float)x, (float)yg, depth);
 }
 
 // U = uint32_t / v2u: the three packed G-buffer texels of the pixel(s)
@@ -552,12 +563,12 @@ DEV float acos01(float x)
 }
 #endif
 template <typename PRM>
-DEV void sky_radiance(const PRM &p, uint32_t x, uint32_t y, float d, float r3[3])   // sky_hosek_frag.glsl:28-60
+DEV void sky_radiance(const PRM &p, uint32_t x, uint32_t yg, float d, float r3[3])   // sky_hosek_frag.glsl:28-60 (yg: frame row)
 {
     const float *A = p.hw[0], *B = p.hw[1], *C = p.hw[2], *D = p.hw[3], *E = p.hw[4], *F = p.hw[5], *G = p.hw[6], *H = p.hw[7],
                 *I = p.hw[8], *Z = p.hw[9], *sun = p.hw[10];
 #if MIL_STRICT
-    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)(y + p.y_offset) + 0.5f) / p.res_y;
+    float cx = ((float)x + 0.5f) / p.res_x, cy = ((float)yg + 0.5f) / p.res_y;
     float px = cx * 2.0f - 1.0f, py = cy * 2.0f - 1.0f;
     float vx = mrow(p.inv_proj, 0, px, py, d, 1.0f), vy = mrow(p.inv_proj, 1, px, py, d, 1.0f);
     float vz = mrow(p.inv_proj, 2, px, py, d, 1.0f), vw = mrow(p.inv_proj, 3, px, py, d, 1.0f);
@@ -575,7 +586,7 @@ DEV void sky_radiance(const PRM &p, uint32_t x, uint32_t y, float d, float r3[3]
         r3[c] = ((left * right) * Z[c]) * 0.05f;                                                 // :51, :58
     }
 #else
-    const float xf = (float)x, yf = (float)(y + p.y_offset);
+    const float xf = (float)x, yf = (float)yg;
     const float *m = p.pos_m;
     // direction only: the w divide of PositionFromDepth is a positive scale the normalisation removes
     f3 v = { __builtin_fmaf(m[0], xf, __builtin_fmaf(m[1], yf, __builtin_fmaf(m[2], d, m[3]))),
@@ -645,9 +656,9 @@ DEV uint32_t encode_ldr(float r, float g, float b, const uint8_t *lut11, const u
     return (uint32_t)lut10[cb] | ((uint32_t)lut11[cg] << 8) | ((uint32_t)lut11[cr] << 16) | 0xFF000000u;
 }
 template <int FMT>
-DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t y, f3 res, float alpha = 1.0f)
+DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t yo, f3 res, float alpha = 1.0f)   // yo: output row
 {
-    size_t o = (size_t)y * p.out_pitch + x;
+    size_t o = (size_t)yo * p.out_pitch + x;
     if (FMT == FMT_HDR) {
         __builtin_nontemporal_store(v4f{ res.x, res.y, res.z, alpha }, (v4f *)p.out + o);   // fs_deferred_lighting.glsl:66
     } else {
@@ -667,14 +678,14 @@ DEV void store_zero(void *out, uint32_t out_pitch, uint32_t x, uint32_t y)
 // to this pixel happens in registers before the one store - sky where the depth is still the clear value
 // (render/mod.rs:221-226), then the transparency resolve blend (render/mod.rs:282-294), then the tonemap/pack of FMT
 // (render/mod.rs:297-309).  hdr is a transient attachment in the reference (pbr/mod.rs:76-95); here it never exists.
-DEV v4f frame_value(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f3 res, const uint32_t *tile)
+DEV v4f frame_value(const ShadeParams &p, uint32_t x, uint32_t y, RowMap rm, float depth, f3 res, const uint32_t *tile)
 {
     v4f h = { res.x, res.y, res.z, 1.0f };
     if (p.has_sky) {
         const bool sky = depth >= MIL_SKY_DEPTH;
         if (__builtin_amdgcn_ballot_w64(sky) != 0) {
             float r3[3];
-            sky_radiance(p, x, y, depth, r3);
+            sky_radiance(p, x, y + rm.g, depth, r3);
             if (sky) h = v4f{ r3[0], r3[1], r3[2], 1.0f };
         }
     }
@@ -702,11 +713,11 @@ DEV v4f frame_value(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f
     return h;
 }
 template <int FMT, bool FRAME>
-DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, float depth, f3 res, const uint32_t *tile = nullptr)
+DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, RowMap rm, float depth, f3 res, const uint32_t *tile = nullptr)
 {
-    if (!FRAME) { store_pixel<FMT>(p, x, y, res); return; }
-    const v4f h = frame_value(p, x, y, depth, res, tile);
-    store_pixel<FMT>(p, x, y, f3{ h.x, h.y, h.z }, h.w);
+    if (!FRAME) { store_pixel<FMT>(p, x, y + rm.o, res); return; }
+    const v4f h = frame_value(p, x, y, rm, depth, res, tile);
+    store_pixel<FMT>(p, x, y + rm.o, f3{ h.x, h.y, h.z }, h.w);
 }
 // the same store through pointers fetched earlier (see k_tiled's unlit tiles)
 template <int FMT>
@@ -724,10 +735,10 @@ DEV void store_pixel_to(void *out, uint32_t out_pitch, const uint8_t *lut11, con
 // Handles directional lights, shadow by direct taps, brute-force point lights, ambient.
 // ---------------------------------------------------------------------------------
 template <int FMT, bool EXT, bool FRAME>
-DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, uint32_t u1, uint32_t u2, uint32_t u3, float depth, DirRec d0)
+DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, RowMap rm, uint32_t u1, uint32_t u2, uint32_t u3, float depth, DirRec d0)
 {
     Px q;
-    setup_pixel(q, p, pixel_position(p, x, y, depth), u1, u2, u3);
+    setup_pixel(q, p, pixel_position(p, x, y + rm.g, depth), u1, u2, u3);
     f3 res = { 0.0f, 0.0f, 0.0f };
     float shadow = 1.0f;
     const bool sh = EXT && p.has_shadow;
@@ -742,7 +753,7 @@ DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, uint32
         for (uint32_t l = 0; l < p.n_point; l++) add_point(q, point_rec_a(p, l), point_rec_b(p, l), res);
         if (p.has_ambient) add_ambient(q, p, u2, res);
     }
-    emit_pixel<FMT, FRAME>(p, x, y, depth, res);
+    emit_pixel<FMT, FRAME>(p, x, y, rm, depth, res);
 }
 
 template <typename T> DEV T sel4(uint32_t j, T a, T b, T c, T d) { return j == 0 ? a : (j == 1 ? b : (j == 2 ? c : d)); }
@@ -761,15 +772,16 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
         const float depth = __builtin_nontemporal_load(p.depth + i);
         const DirRec d0 = dir_rec(p, 0);
         if (x >= p.width || y > ylast) return;
+        const RowMap rm = row_map(p, blockIdx.y * 4);
 #if !MIL_STRICT
         // extensions on: a wave whose 64 pixels all have occlusion 0 (cleared G-buffer) writes its exact zeros
         // and skips shadow taps, point lights and BRDF (the same early-out as k_tiled)
         if (EXT && __builtin_amdgcn_ballot_w64((u2 >> 24) != 0) == 0) {
-            emit_pixel<FMT, FRAME>(p, x, y, depth, f3{ 0.0f, 0.0f, 0.0f });
+            emit_pixel<FMT, FRAME>(p, x, y, rm, depth, f3{ 0.0f, 0.0f, 0.0f });
             return;
         }
 #endif
-        shade_stream_pixel<FMT, EXT, FRAME>(p, x, y, u1, u2, u3, depth, d0);
+        shade_stream_pixel<FMT, EXT, FRAME>(p, x, y, rm, u1, u2, u3, depth, d0);
         return;
     }
     const uint32_t y0 = blockIdx.y * 16 + threadIdx.y;     // this lane: rows y0, y0+4, y0+8, y0+12
@@ -783,11 +795,12 @@ __global__ __launch_bounds__(256) void k_stream(const ShadeParams p)
     }
     const DirRec d0 = dir_rec(p, 0);
     if (x >= p.width) return;
+    const RowMap rm = row_map(p, blockIdx.y * 16);
 #pragma unroll 1
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t y = y0 + 4 * j;
         if (y > ylast) break;
-        shade_stream_pixel<FMT, EXT, FRAME>(p, x, y, sel4(j, u1[0], u1[1], u1[2], u1[3]), sel4(j, u2[0], u2[1], u2[2], u2[3]),
+        shade_stream_pixel<FMT, EXT, FRAME>(p, x, y, rm, sel4(j, u1[0], u1[1], u1[2], u1[3]), sel4(j, u2[0], u2[1], u2[2], u2[3]),
                                      sel4(j, u3[0], u3[1], u3[2], u3[3]), sel4(j, dz[0], dz[1], dz[2], dz[3]), d0);
     }
 }
@@ -810,15 +823,16 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
     const v2u u3 = { __builtin_nontemporal_load(p.rm + ia), __builtin_nontemporal_load(p.rm + ib) };
     const v2f depth = { __builtin_nontemporal_load(p.depth + ia), __builtin_nontemporal_load(p.depth + ib) };
     if (x >= p.width || ya > ylast) return;
+    const RowMap rm = row_map(p, blockIdx.y * 8);
     const bool inB = yb <= ylast;
     const bool litA = (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
     if (__builtin_amdgcn_ballot_w64(litA || litB) == 0) {
-        emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ 0.0f, 0.0f, 0.0f });
-        if (inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ 0.0f, 0.0f, 0.0f });
+        emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ 0.0f, 0.0f, 0.0f });
+        if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ 0.0f, 0.0f, 0.0f });
         return;
     }
     Px2 q;
-    setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + p.y_offset), (float)(yb + p.y_offset) }, depth), u1, w2, u3);
+    setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth), u1, w2, u3);
     V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
     const bool sh = EXT && p.has_shadow && p.n_dir > 0;
     v2f shadow = { 1.0f, 1.0f };
@@ -845,8 +859,8 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
             r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
         }
     }
-    emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ r.x.x, r.y.x, r.z.x });
-    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ r.x.y, r.y.y, r.z.y });
+    emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
+    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
 }
 #endif
 
@@ -986,11 +1000,13 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const uint32_t k_n_point = p.n_point, k_has_shadow = p.has_shadow, k_n_dir = p.n_dir, k_shadow_lds = p.shadow_lds;
     const uint32_t k_tune = p.tune, k_tiles_x = p.tiles_x, k_tiles_y = p.tiles_y, k_width = p.width, k_height = p.height, k_pitch = p.pitch;
     const uint32_t k_resolve_dma = FRAME ? p.resolve_dma : 0u, k_has_sky = FRAME ? p.has_sky : 0u;
+    const uint32_t k_y_offset = p.y_offset, k_band_shift = p.band_shift, k_band_extra = p.band_extra, k_out_band_extra = p.out_band_extra;
     const uint32_t *const k_albedo = p.albedo;
     const uint16_t *const k_accum = FRAME ? p.accum : nullptr;
     uint32_t *const k_stamps = p.tile_stamps;
     asm volatile("" :: "s"(k_n_point), "s"(k_has_shadow), "s"(k_n_dir), "s"(k_shadow_lds), "s"(k_tune), "s"(k_tiles_x), "s"(k_tiles_y),
-                 "s"(k_width), "s"(k_height), "s"(k_pitch), "s"(k_resolve_dma), "s"(k_has_sky), "s"(k_albedo), "s"(k_accum), "s"(k_stamps));
+                 "s"(k_width), "s"(k_height), "s"(k_pitch), "s"(k_resolve_dma), "s"(k_has_sky), "s"(k_albedo), "s"(k_accum), "s"(k_stamps),
+                 "s"(k_y_offset), "s"(k_band_shift), "s"(k_band_extra), "s"(k_out_band_extra));
     const bool do_shadow = k_has_shadow && k_n_dir > 0;
     const bool stage = do_shadow && k_shadow_lds;
     // whole frame with a resolve: the tile's accum / revealage texels ride the LDS-DMA with the G-buffer planes, so their
@@ -1012,6 +1028,9 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const uint32_t ri = blk / bpr, tyi = (k_tune & 1u) || k_tiles_y > MIL_MAX_ROW_ORDER ? ri : (uint32_t)p.row_order[ri];
     const uint32_t txi = (blk - ri * bpr) * wpb + wv;
     if (txi >= k_tiles_x) return;                       // whole wave; nothing below synchronises across waves
+    // frame row / output row of this tile's local rows (band dealing: a tile never straddles two bands)
+    const uint32_t k_band = (tyi * TILE) >> k_band_shift;
+    const RowMap rm = { k_y_offset + k_band * k_band_extra, k_band * k_out_band_extra };
     const uint64_t t_start = k_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
 
     // ---- 1. HBM -> LDS, coordinates clamped (not branched) so the loads are straight-line ----
@@ -1065,14 +1084,14 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (xin && (y0 + 4 * j) <= ylast)
-                            h[j] = frame_value(p, x, y0 + 4 * j, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+                            h[j] = frame_value(p, x, y0 + 4 * j, rm, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j, h[j]);
+                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j + rm.o, h[j]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j);
+                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j + rm.o);
                 }
                 if (e_counts && lane == 0) e_counts[tyi * k_tiles_x + txi] = 0;
                 if (k_stamps && lane == 0) {
@@ -1112,7 +1131,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         f3 P4[4];    // the same packed evaluation as the shading passes (rows j, j + 1 together): identical positions
 #pragma unroll
         for (int jj = 0; jj < 4; jj += 2) {
-            const PosT<v2f> q2 = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(y0 + 4 * jj + p.y_offset), (float)(y0 + 4 * jj + 4 + p.y_offset) },
+            const PosT<v2f> q2 = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(y0 + 4 * jj + rm.g), (float)(y0 + 4 * jj + 4 + rm.g) },
                                                        v2f{ __uint_as_float(s_tex[(12 + jj) * 64 + lane]), __uint_as_float(s_tex[(13 + jj) * 64 + lane]) });
             P4[jj] = f3{ q2.P.x.x, q2.P.y.x, q2.P.z.x }; P4[jj + 1] = f3{ q2.P.x.y, q2.P.y.y, q2.P.z.y };
         }
@@ -1120,7 +1139,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
 #if MIL_STRICT
-            const f3 P = pixel_position(p, x, y0 + 4 * j, __uint_as_float(s_tex[(12 + j) * 64 + lane])).P;
+            const f3 P = pixel_position(p, x, y0 + 4 * j + rm.g, __uint_as_float(s_tex[(12 + j) * 64 + lane])).P;
 #else
             const f3 P = P4[j];
 #endif
@@ -1233,7 +1252,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             const float depth = __uint_as_float(s_tex[(12 + j) * 64 + lane]);
             const bool inbj = xin && y <= ylast, litj = inbj && (w2 >> 24) != 0;
             Px q;
-            setup_pixel(q, p, pixel_position(p, x, y, depth), u1, w2, u3);
+            setup_pixel(q, p, pixel_position(p, x, y + rm.g, depth), u1, w2, u3);
             f3 r = { 0.0f, 0.0f, 0.0f };
             if (first) {
                 float shadow = 1.0f;
@@ -1264,7 +1283,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             }
             if (last) {
                 if (p.has_ambient) add_ambient(q, p, w2, r);
-                if (inbj) emit_pixel<FMT, FRAME>(p, x, y, depth, r, s_resolve);
+                if (inbj) emit_pixel<FMT, FRAME>(p, x, y, rm, depth, r, s_resolve);
             } else {
                 s_res[j * 64 + lane] = r.x; s_res[256 + j * 64 + lane] = r.y; s_res[512 + j * 64 + lane] = r.z;
             }
@@ -1285,12 +1304,12 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             // fs_deferred_lighting.glsl:63 and of the extensions: the pixel is exactly 0.  When none of the
             // pass's 128 pixels is lit the wave writes the zeros and skips the shading altogether.
             if (__builtin_amdgcn_ballot_w64(litA || litB) == 0) {
-                if (last && inA) emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
-                if (last && inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+                if (last && inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+                if (last && inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
                 continue;
             }
             Px2 q;
-            setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + p.y_offset), (float)(yb + p.y_offset) }, depth),
+            setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth),
                                     u1, w2, u3);
             V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
             if (first) {
@@ -1334,8 +1353,8 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                     r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
                     r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
                 }
-                if (inA) emit_pixel<FMT, FRAME>(p, x, ya, depth.x, f3{ r.x.x, r.y.x, r.z.x }, s_resolve);
-                if (inB) emit_pixel<FMT, FRAME>(p, x, yb, depth.y, f3{ r.x.y, r.y.y, r.z.y }, s_resolve);
+                if (inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x }, s_resolve);
+                if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y }, s_resolve);
             } else {
                 s_res[ja * 64 + lane] = r.x.x; s_res[(ja + 1) * 64 + lane] = r.x.y;
                 s_res[256 + ja * 64 + lane] = r.y.x; s_res[256 + (ja + 1) * 64 + lane] = r.y.y;
@@ -1382,7 +1401,7 @@ __global__ __launch_bounds__(256) void k_count_pairs(const ShadeParams p, unsign
     if (x < p.width && y < p.height) {
         size_t i = (size_t)y * p.pitch + x;
         Px q;
-        setup_pixel(q, p, pixel_position(p, x, y, p.depth[i]), p.normal[i], p.albedo[i], p.rm[i]);
+        setup_pixel(q, p, pixel_position(p, x, y + row_map(p, blockIdx.y * 4).g, p.depth[i]), p.normal[i], p.albedo[i], p.rm[i]);
         if (q.occ > 0.0f)
             for (uint32_t l = 0; l < p.n_point; l++) {
                 v4f a = ldu(p.point_prep, 2 * l);
@@ -1605,7 +1624,7 @@ __global__ __launch_bounds__(256) void k_sky(const SkyParams p)
     const bool sky = d >= MIL_SKY_DEPTH;
     if (__builtin_amdgcn_ballot_w64(sky) == 0) return;
     float r3[3];
-    sky_radiance(p, x, y, d, r3);
+    sky_radiance(p, x, y + p.y_offset, d, r3);
     if (sky) __builtin_nontemporal_store(v4f{ r3[0], r3[1], r3[2], 1.0f }, (v4f *)p.hdr + (size_t)y * p.hdr_pitch + x);
 }
 
@@ -1712,18 +1731,24 @@ __global__ __launch_bounds__(256) void k_accumulate(const AccumParams p)
 }
 
 // ---------------------------------------------------------------------------------
-// launchers (host)
+// launchers (host).  Each returns the status of its own hipLaunchKernel call: hipGetLastError would also return (and
+// clear) errors that other HIP users of the calling thread left behind.
 // ---------------------------------------------------------------------------------
-void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
+template <typename P> static inline hipError_t launch_k(void (*kernel)(P), dim3 grid, dim3 block, size_t lds, hipStream_t s, const P &p)
+{
+    void *args[] = { (void *)&p };
+    return hipLaunchKernel((const void *)kernel, grid, block, args, lds, s);
+}
+hipError_t launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {
     const bool ext = p.has_shadow || p.n_point || p.has_ambient;
 #if !MIL_STRICT
     if (!(p.tune & 256u) && p.rows_per_block != 4) {      // two pixels per lane, packed (MIL_TUNE bit 256: the one-pixel kernel)
         dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 7) / 8);
 #define MIL_LAUNCH_STREAM2(F)                                                                  \
-        if (frame) hipLaunchKernelGGL((k_stream2<F, true, true>), grid, block, 0, s, p);         \
-        else if (ext) hipLaunchKernelGGL((k_stream2<F, true, false>), grid, block, 0, s, p);     \
-        else hipLaunchKernelGGL((k_stream2<F, false, false>), grid, block, 0, s, p);
+        if (frame) return launch_k(k_stream2<F, true, true>, grid, block, 0, s, p);         \
+        else if (ext) return launch_k(k_stream2<F, true, false>, grid, block, 0, s, p);     \
+        else return launch_k(k_stream2<F, false, false>, grid, block, 0, s, p);
         switch (fmt) {
         case FMT_HDR: MIL_LAUNCH_STREAM2(FMT_HDR); break;
         case FMT_LDR: MIL_LAUNCH_STREAM2(FMT_LDR); break;
@@ -1731,17 +1756,16 @@ void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
         default: MIL_LAUNCH_STREAM2(FMT_SRGB8_VIA_LDR); break;
         }
 #undef MIL_LAUNCH_STREAM2
-        return;
     }
 #endif
     const bool four = p.rows_per_block == 4 && !frame;
     dim3 block(64, 4), grid((p.width + 63) / 64, four ? (p.height + 15) / 16 : (p.height + 3) / 4);
 #define MIL_LAUNCH_STREAM(F)                                                                     \
-    if (frame) hipLaunchKernelGGL((k_stream<F, 1, true, true>), grid, block, 0, s, p);             \
-    else if (four) { if (ext) hipLaunchKernelGGL((k_stream<F, 4, true, false>), grid, block, 0, s, p);  \
-                     else hipLaunchKernelGGL((k_stream<F, 4, false, false>), grid, block, 0, s, p); }   \
-    else { if (ext) hipLaunchKernelGGL((k_stream<F, 1, true, false>), grid, block, 0, s, p);       \
-           else hipLaunchKernelGGL((k_stream<F, 1, false, false>), grid, block, 0, s, p); }
+    if (frame) return launch_k(k_stream<F, 1, true, true>, grid, block, 0, s, p);             \
+    else if (four) { if (ext) return launch_k(k_stream<F, 4, true, false>, grid, block, 0, s, p);  \
+                     else return launch_k(k_stream<F, 4, false, false>, grid, block, 0, s, p); }   \
+    else { if (ext) return launch_k(k_stream<F, 1, true, false>, grid, block, 0, s, p);       \
+           else return launch_k(k_stream<F, 1, false, false>, grid, block, 0, s, p); }
     switch (fmt) {
     case FMT_HDR: MIL_LAUNCH_STREAM(FMT_HDR); break;
     case FMT_LDR: MIL_LAUNCH_STREAM(FMT_LDR); break;
@@ -1749,15 +1773,16 @@ void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
     default: MIL_LAUNCH_STREAM(FMT_SRGB8_VIA_LDR); break;
     }
 #undef MIL_LAUNCH_STREAM
+    return hipErrorInvalidValue;    // not reached: every case returns
 }
-void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
+hipError_t launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {
     const uint32_t wpb = (p.tune & 2u) ? 1 : ((p.tune & 4u) ? 2 : 4);
     dim3 block(64 * wpb), grid(((p.tiles_x + wpb - 1) / wpb) * p.tiles_y);
     const size_t lds = (size_t)wpb * tiled_lds(p.n_point, p.has_shadow && p.shadow_lds && p.n_dir, frame && p.accum && p.resolve_dma).per_wave;
 #define MIL_LAUNCH_TILED(F)                                                             \
-    if (frame) hipLaunchKernelGGL((k_tiled<F, true>), grid, block, lds, s, p);            \
-    else hipLaunchKernelGGL((k_tiled<F, false>), grid, block, lds, s, p);
+    if (frame) return launch_k(k_tiled<F, true>, grid, block, lds, s, p);            \
+    else return launch_k(k_tiled<F, false>, grid, block, lds, s, p);
     switch (fmt) {
     case FMT_HDR: MIL_LAUNCH_TILED(FMT_HDR); break;
     case FMT_LDR: MIL_LAUNCH_TILED(FMT_LDR); break;
@@ -1765,56 +1790,59 @@ void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
     default: MIL_LAUNCH_TILED(FMT_SRGB8_VIA_LDR); break;
     }
 #undef MIL_LAUNCH_TILED
+    return hipErrorInvalidValue;    // not reached: every case returns
 }
-void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
+hipError_t launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s)
 {
     const uint32_t rows = p.rows == 1 || p.rows == 4 ? p.rows : 2;
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 4 * rows - 1) / (4 * rows));
 #define MIL_LAUNCH_TONEMAP(F)                                                               \
-    if (rows == 1) hipLaunchKernelGGL((k_tonemap<F, 1>), grid, block, 0, s, p);               \
-    else if (rows == 2) hipLaunchKernelGGL((k_tonemap<F, 2>), grid, block, 0, s, p);          \
-    else hipLaunchKernelGGL((k_tonemap<F, 4>), grid, block, 0, s, p);
+    if (rows == 1) return launch_k(k_tonemap<F, 1>, grid, block, 0, s, p);               \
+    else if (rows == 2) return launch_k(k_tonemap<F, 2>, grid, block, 0, s, p);          \
+    else return launch_k(k_tonemap<F, 4>, grid, block, 0, s, p);
     switch (fmt) {
     case FMT_LDR: MIL_LAUNCH_TONEMAP(FMT_LDR); break;
     case FMT_SRGB8: MIL_LAUNCH_TONEMAP(FMT_SRGB8); break;
     default: MIL_LAUNCH_TONEMAP(FMT_SRGB8_VIA_LDR); break;
     }
 #undef MIL_LAUNCH_TONEMAP
+    return hipErrorInvalidValue;    // not reached: every case returns
 }
-void launch_fxaa(const FxaaParams &p, hipStream_t s)
+hipError_t launch_fxaa(const FxaaParams &p, hipStream_t s)
 {
 #if MIL_STRICT
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.row_count + 3) / 4);
-    hipLaunchKernelGGL(k_fxaa, grid, block, 0, s, p);
+    return launch_k(k_fxaa, grid, block, 0, s, p);
 #else
     if (p.rows == 2) {
         dim3 block(64, 4), grid((p.width + 61) / 62, (p.row_count + 7) / 8);
-        hipLaunchKernelGGL(k_fxaa2<2>, grid, block, 0, s, p);
+        return launch_k(k_fxaa2<2>, grid, block, 0, s, p);
     } else {
         dim3 block(64, 4), grid((p.width + 61) / 62, (p.row_count + 15) / 16);
-        hipLaunchKernelGGL(k_fxaa2<4>, grid, block, 0, s, p);
+        return launch_k(k_fxaa2<4>, grid, block, 0, s, p);
     }
 #endif
 }
-void launch_sky(const SkyParams &p, hipStream_t s)
+hipError_t launch_sky(const SkyParams &p, hipStream_t s)
 {
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
-    hipLaunchKernelGGL(k_sky, grid, block, 0, s, p);
+    return launch_k(k_sky, grid, block, 0, s, p);
 }
-void launch_resolve(const ResolveParams &p, hipStream_t s)
+hipError_t launch_resolve(const ResolveParams &p, hipStream_t s)
 {
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
-    hipLaunchKernelGGL(k_resolve, grid, block, 0, s, p);
+    return launch_k(k_resolve, grid, block, 0, s, p);
 }
-void launch_accumulate(const AccumParams &p, hipStream_t s)
+hipError_t launch_accumulate(const AccumParams &p, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_accumulate, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
+    return launch_k(k_accumulate, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
 }
 #if !MIL_STRICT
-void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)
+hipError_t launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)
 {
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);
-    hipLaunchKernelGGL(k_count_pairs, grid, block, 0, s, p, count);
+    void *args[] = { (void *)&p, (void *)&count };
+    return hipLaunchKernel((const void *)k_count_pairs, grid, block, args, 0, s);
 }
 #endif
 

@@ -1,0 +1,77 @@
+// Host-side internals of libmil.so shared by mil_api.cpp (single-GPU entry points) and mil_mg.cpp (multi-GPU strips /
+// frames + gather).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mil.h"
+#include "mil_params.h"
+
+namespace milhost {
+
+constexpr int RING = 4;
+constexpr int SLOT_STREAMS = 4;
+constexpr uint32_t LUT11_N = 0x3C1, LUT10_N = 0x1E1;
+
+// One staged copy of a call's light arrays.  Layout of `host` and `dev` (dir_b = MIL_MAX_DIR_LIGHTS * 32,
+// pt_b = capacity * 32): dir_raw | dir_prep | point_raw | point_prep (n x 32 bytes each) | point_cull (n x 16).
+struct Slot {
+    uint8_t *host = nullptr; // pinned
+    uint8_t *dev = nullptr;
+    // The last kernel that read this slot, PER STREAM: every call names its own stream, and a slot may be recycled only
+    // when its readers on all of them are done.
+    hipEvent_t done[SLOT_STREAMS] = {};
+    hipStream_t done_stream[SLOT_STREAMS] = {};
+    bool done_used[SLOT_STREAMS] = {};
+    hipEvent_t staged = nullptr; // upload of this slot's content finished (recorded on the copy stream)
+    bool valid = false;          // holds staged content
+    uint32_t n_dir = 0, n_point = 0;
+    uint64_t gen = 0;            // bumped whenever new content is staged into this slot
+};
+
+// Light arrays that already lie in device memory in the slot layout (prepared there by a kernel on the caller's stream):
+// nothing is staged, recorded or waited for.
+struct PreStaged {
+    const uint8_t *dev;
+    uint32_t capacity;           // point-light capacity the layout was cut for
+};
+
+} // namespace milhost
+
+struct mil_ctx {
+    int device = 0;
+    uint32_t max_point = 0;
+    size_t slot_bytes = 0;
+    milhost::Slot ring[milhost::RING];
+    int next = 0, cur = -1;      // cur: slot holding the most recently used content
+    uint64_t gen = 0;
+    uint8_t *scratch = nullptr;  // host: the content of this call, built before it is compared with the ring
+    hipStream_t copy_stream = nullptr;
+    uint8_t *lut = nullptr;      // device: lut11 then lut10
+    uint32_t *tile_counts = nullptr, *tile_stamps = nullptr;
+    uint32_t tile_counts_cap = 0, tile_stamps_cap = 0;   // tiles the diagnostic buffers hold
+    uint32_t tune = 0;
+    uint16_t row_order[MIL_MAX_ROW_ORDER];   // last computed K2 row order and what it was computed from (order_rows)
+    uint8_t row_key[192];
+    bool row_key_valid = false;
+    uint32_t tonemap_rows = 0;   // K4 rows per lane            } tuning knobs: read from the environment only when
+    uint32_t fxaa_rows = 2;      // K5 output rows per lane      } MIL_DEBUG=1 is set (mil_create); the defaults are what
+    uint32_t k1_rows = 1;        // K1 pixels per lane           } the parity suite covers
+    int last_hip = 0;
+};
+
+namespace milhost {
+
+int hip_fail(mil_ctx *c, hipError_t e);
+int set_device(mil_ctx *c);
+
+// mil_light_ex / mil_shade_frame / mil_shade_bands: one routine.
+//   bands       NULL = the planes are a strip of contiguous rows
+//   out_frame   with bands: `out` is the assembled frame (rows of the whole frame) instead of the compacted local rows
+//   pre         NULL = stage the host light arrays through the ring; else they are already on the device
+int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_directional_light *lights,
+          const mil_push_constants *push, const mil_extras *ex, const mil_frame_passes *passes, void *out,
+          uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream, const mil_band_layout *bands,
+          bool out_frame, const PreStaged *pre);
+
+} // namespace milhost

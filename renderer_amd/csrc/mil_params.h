@@ -16,6 +16,11 @@ struct ShadeParams {
     const uint32_t *normal, *albedo, *rm;
     const float *depth;
     uint32_t width, height, pitch, y_offset;
+    // Band dealing (multi-GPU, mil_band_layout): the planes hold every n-th band of band_rows = 1 << band_shift rows of the
+    // frame, compacted.  global row = local + y_offset + (local >> band_shift) * band_extra, band_extra = (n - 1) * band_rows
+    // (y_offset carries rank * band_rows).  Off: band_shift = band_extra = 0 and the formula is the strip's local + y_offset.
+    // The output is indexed by local rows, or (out_band_extra = band_extra) by rows of the assembled frame.
+    uint32_t band_shift, band_extra, out_band_extra;
     // FrameMatrixData subset read by the lighting shader (fs_deferred_lighting.glsl:34-36,59)
     float inv_proj[16], inv_view[16], cam[3];
     float res_x, res_y;     // push_constants.resolution
@@ -97,25 +102,26 @@ struct AccumParams {          // transparency accumulate over a fragment list (f
     const float4 *dir_raw;                      // (the shader does not use the intensity)
 };
 
-// implemented once per numeric mode
+// implemented once per numeric mode; every launcher returns the status of ITS OWN launch (hipLaunchKernel), not the
+// thread's sticky error state
 namespace fast {
-void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
-void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
-void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
-void launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
-void launch_fxaa(const FxaaParams &p, hipStream_t s);
-void launch_sky(const SkyParams &p, hipStream_t s);
-void launch_resolve(const ResolveParams &p, hipStream_t s);
-void launch_accumulate(const AccumParams &p, hipStream_t s);
+hipError_t launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
+hipError_t launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
+hipError_t launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
+hipError_t launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
+hipError_t launch_fxaa(const FxaaParams &p, hipStream_t s);
+hipError_t launch_sky(const SkyParams &p, hipStream_t s);
+hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
+hipError_t launch_accumulate(const AccumParams &p, hipStream_t s);
 }
 namespace strict {
-void launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
-void launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
-void launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
-void launch_fxaa(const FxaaParams &p, hipStream_t s);
-void launch_sky(const SkyParams &p, hipStream_t s);
-void launch_resolve(const ResolveParams &p, hipStream_t s);
-void launch_accumulate(const AccumParams &p, hipStream_t s);
+hipError_t launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
+hipError_t launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
+hipError_t launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
+hipError_t launch_fxaa(const FxaaParams &p, hipStream_t s);
+hipError_t launch_sky(const SkyParams &p, hipStream_t s);
+hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);
+hipError_t launch_accumulate(const AccumParams &p, hipStream_t s);
 }
 
 } // namespace mil

@@ -26,7 +26,7 @@ EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'm
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
            'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame',
            'mil_transparency_accumulate', 'mil_import_external_memory', 'mil_alloc_exportable_memory',
-           'mil_release_external_memory']
+           'mil_release_external_memory', 'mil_shade_bands', 'mil_band_local_rows', 'mil_row_weights']
 
 
 class MilError(RuntimeError):
@@ -55,6 +55,10 @@ class FramePasses(ctypes.Structure):      # mil_frame_passes
                 ('accum_pitch_px', ctypes.c_uint32), ('reveal_pitch_px', ctypes.c_uint32)]
 
 
+class BandLayout(ctypes.Structure):        # mil_band_layout
+    _fields_ = [('band_rows', ctypes.c_uint32), ('n_ranks', ctypes.c_uint32), ('rank', ctypes.c_uint32)]
+
+
 class TransparentFragments(ctypes.Structure):   # mil_transparent_fragments
     _fields_ = [('position_depth', ctypes.c_void_p), ('normal_opacity', ctypes.c_void_p),
                 ('albedo_roughness', ctypes.c_void_p), ('metallic', ctypes.c_void_p), ('count', ctypes.c_uint32)]
@@ -81,8 +85,8 @@ def load_library(path=LIB_PATH):
         lib.mil_destroy.argtypes = [ctypes.c_void_p]
         lib.mil_destroy.restype = None
         lib.mil_last_hip_error.argtypes = [ctypes.c_void_p]
-        lib.mil_set_tile_count_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-        lib.mil_set_tile_stamp_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.mil_set_tile_count_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+        lib.mil_set_tile_stamp_buffer.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
         lib.mil_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         vp, u32 = ctypes.c_void_p, ctypes.c_uint32
         lib.mil_light_directional.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, vp, u32, u32, vp]
@@ -100,12 +104,45 @@ def load_library(path=LIB_PATH):
                                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
         lib.mil_release_external_memory.argtypes = [vp, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
+        lib.mil_shade_bands.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras),
+                                        ctypes.POINTER(FramePasses), ctypes.POINTER(BandLayout), vp, u32, ctypes.c_int,
+                                        ctypes.c_int, u32, vp]
+        lib.mil_band_local_rows.argtypes = [ctypes.POINTER(BandLayout), u32]
+        lib.mil_band_local_rows.restype = u32
+        lib.mil_row_weights.argtypes = [vp, vp, u32, u32, ctypes.POINTER(BandLayout), vp, u32, vp]
         _lib = lib
     return _lib
 
 
 def _np_ptr(a):
     return ctypes.c_void_p(a.ctypes.data)
+
+
+def band_local_rows(height, band_rows, n_ranks, rank):
+    """Rows rank `rank` holds when the frame's bands of band_rows rows are dealt cyclically over n_ranks (host arithmetic)."""
+    return int(load_library().mil_band_local_rows(ctypes.byref(BandLayout(band_rows, n_ranks, rank)), height))
+
+
+def band_rows_of_rank(height, band_rows, n_ranks, rank):
+    """Frame rows of that rank in local order (numpy int64): local row k is frame row result[k]."""
+    nb = -(-height // band_rows)
+    rows = [np.arange(b * band_rows, min(height, (b + 1) * band_rows)) for b in range(rank, nb, n_ranks)]
+    return np.concatenate(rows) if rows else np.zeros(0, np.int64)
+
+
+def row_weights(frame, width, height, point_lights, gb_height=None, y_offset=0, bands=None):
+    """mil_row_weights: the K2 launch-order weight of every local 16-row tile row (host arithmetic; works without a GPU)."""
+    lib = load_library()
+    gb_height = height if gb_height is None else gb_height
+    frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+    pl = np.ascontiguousarray(point_lights, np.float32).reshape(-1, 8)
+    push = ubo.push_constants(width, height, 0)
+    w = np.zeros((gb_height + TILE - 1) // TILE, np.uint32)
+    b = ctypes.byref(BandLayout(*bands)) if bands is not None else None
+    rc = lib.mil_row_weights(_np_ptr(frame), _np_ptr(push), gb_height, y_offset, b, _np_ptr(pl), pl.shape[0], _np_ptr(w))
+    if rc != 0:
+        raise MilError(f'mil error {rc}: {lib.mil_strerror(rc).decode()}')
+    return w
 
 
 class LightingPass:
@@ -122,6 +159,7 @@ class LightingPass:
         h = ctypes.c_void_p()
         self._check(self.lib.mil_create(ctypes.byref(h), device, max_point_lights), None)
         self.ctx = h
+        self._tile_counts = self._tile_stamps = None     # diagnostic buffers the ctx points at: kept alive here
 
     def close(self):
         if getattr(self, 'ctx', None):
@@ -282,7 +320,27 @@ class LightingPass:
             fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
         return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream)
 
-    def _shade(self, gb, frame, lights, point_lights, ambient, shadow, passes, fmt, flags, out, stream):
+    def shade_bands(self, gb, frame, lights, bands, point_lights=None, ambient=None, shadow=None, sky=None, accum=None,
+                    reveal=None, fmt=OUT_LDR, flags=0, out=None, out_is_frame=False, stream=None):
+        """mil_shade_bands: mil_shade_frame on a rank's dealt bands.  gb: the rank's compacted planes with width / height
+        of the WHOLE frame in gb['width'] / gb['height']; bands = (band_rows, n_ranks, rank).  out: the rank's compacted
+        output, or (out_is_frame) the assembled frame."""
+        t = self.torch
+        fp = FramePasses()
+        keep = []
+        if sky is not None:
+            prm = np.ascontiguousarray(sky, np.float32).reshape(44)
+            keep.append(prm)
+            fp.sky = prm.ctypes.data
+        if accum is not None:
+            assert accum.dtype == t.float16 and reveal.dtype == t.float16
+            fp.accum, fp.reveal = accum.data_ptr(), reveal.data_ptr()
+            fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
+        return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream,
+                           bands=BandLayout(*bands), out_is_frame=out_is_frame)
+
+    def _shade(self, gb, frame, lights, point_lights, ambient, shadow, passes, fmt, flags, out, stream, bands=None,
+               out_is_frame=False):
         t = self.torch
         h, w = gb['depth'].shape
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros((0, 8)), np.float32).reshape(-1, 8)
@@ -304,11 +362,16 @@ class LightingPass:
             keep.append(sh)
             ex.shadow = ctypes.pointer(sh)
         if out is None:
-            out = (t.empty((h, w, 4), dtype=t.float32, device=self.device) if fmt == OUT_HDR
-                   else t.empty((h, w), dtype=t.int32, device=self.device))
+            oh = gb['height'] if out_is_frame else h
+            out = (t.empty((oh, w, 4), dtype=t.float32, device=self.device) if fmt == OUT_HDR
+                   else t.empty((oh, w), dtype=t.int32, device=self.device))
         pitch = out.stride(0) // 4 if fmt == OUT_HDR else out.stride(0)
         g = self._gb(gb)
-        if passes is None:
+        if bands is not None:
+            self._check(self.lib.mil_shade_bands(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
+                                                 ctypes.byref(ex), ctypes.byref(passes), ctypes.byref(bands), out.data_ptr(),
+                                                 pitch, 1 if out_is_frame else 0, fmt, flags, self._stream(stream)))
+        elif passes is None:
             self._check(self.lib.mil_light_ex(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
                                               ctypes.byref(ex), out.data_ptr(), pitch, fmt, flags, self._stream(stream)))
         else:
@@ -333,7 +396,10 @@ class LightingPass:
         t = self.torch
         h, w = gb['depth'].shape
         buf = t.zeros(((h + TILE - 1) // TILE, (w + TILE - 1) // TILE), dtype=t.int32, device=self.device)
-        self._check(self.lib.mil_set_tile_count_buffer(self.ctx, buf.data_ptr() if enable else None))
+        # the ctx keeps the raw pointer: the tensor lives on self until it is replaced or disabled, and the ctx knows
+        # how many tiles it holds (a larger launch leaves it untouched)
+        self._tile_counts = buf if enable else None
+        self._check(self.lib.mil_set_tile_count_buffer(self.ctx, buf.data_ptr() if enable else None, buf.numel() if enable else 0))
         return buf
 
     def tile_stamps(self, gb, enable=True):
@@ -341,7 +407,8 @@ class LightingPass:
         t = self.torch
         h, w = gb['depth'].shape
         buf = t.zeros(((h + TILE - 1) // TILE, (w + TILE - 1) // TILE, 4), dtype=t.int32, device=self.device)
-        self._check(self.lib.mil_set_tile_stamp_buffer(self.ctx, buf.data_ptr() if enable else None))
+        self._tile_stamps = buf if enable else None
+        self._check(self.lib.mil_set_tile_stamp_buffer(self.ctx, buf.data_ptr() if enable else None, buf.numel() // 4 if enable else 0))
         return buf
 
     def sync(self, stream=None):

@@ -115,6 +115,18 @@ def orbit_camera(frame_idx, n_frames, width, height):
                                  fov_deg=90.0, aspect_ratio=width / height, near=0.05, far=100.0)
 
 
+def animated_point_lights(base, frame_idx, n_frames):
+    """Lights of the frame-parallel config: every light of `base` ((n, 8) float32 rows
+    {position, radius, colour, intensity}) translates sinusoidally, a closed form of the frame index - light k moves
+    along x and z with amplitude 1.5 and phase k * golden angle, one period per n_frames."""
+    pl = np.array(base, np.float32, copy=True).reshape(-1, 8)
+    k = np.arange(pl.shape[0], dtype=np.float64)
+    ph = 2.0 * math.pi * frame_idx / n_frames + k * 2.399963229728653
+    pl[:, 0] = (pl[:, 0].astype(np.float64) + 1.5 * np.sin(ph)).astype(np.float32)
+    pl[:, 2] = (pl[:, 2].astype(np.float64) + 1.5 * np.cos(ph)).astype(np.float32)
+    return pl
+
+
 def gather_strips(local, bounds, full=None, dst=0, group=None, async_op=False):
     """Gather row strips to rank `dst`.  local: this rank's (rows, width, ...) tensor;
     full (rank dst only): (height, width, ...) destination.  Returns the list of pending

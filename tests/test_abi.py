@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     assert sorted(syms) == sorted(lighting.EXPORTS)
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.mil_version() == 1
+    assert lib.mil_version() == 2
     assert lib.mil_strerror(0) == b'ok' and b'bad argument' in lib.mil_strerror(-1)
 
 

@@ -186,6 +186,31 @@ def test_two_restatements_agree(coracle):
     np.testing.assert_array_equal(c, d)
 
 
+def test_f64_c_oracle_equals_numpy(coracle):
+    """oracle/mil_oracle_f64.c (what the full-size GPU tests check the fast path against) is the NumPy float64 oracle
+    to rounding: result and conditioning bound, Scene A and noise, every extension on, strips included."""
+    for kind, (w, h) in (('sweep', (96, 54)), ('noise', (64, 36))):
+        cam = synth.sweep_camera(w, h)
+        gb = synth.to_numpy(synth.scene_sweep(w, h, cam) if kind == 'sweep' else synth.scene_noise(w, h, 5))
+        frame, dl, pl = cam.frame_matrix_data(), ubo.default_directional_lights(), synth.point_light_field(40, 3)
+        sh = synth.shadow_setup(dl[0, 0:3], 128)
+        sh = dict(sh, map=sh['map'].numpy())
+        planes = (gb['normal'], gb['albedo_occ'], gb['rough_metal'], gb['depth'])
+        kw = dict(point_lights=pl, ambient=(0.03, 0.03, 0.03), shadow=sh, want_cond=True)
+        a, ca = mo.shade(*planes, frame, dl, **kw)
+        b, cb = coracle.shade_f64(*planes, frame, dl, **kw)
+        assert np.array_equal(np.isfinite(a), np.isfinite(b))
+        fin = np.isfinite(a)
+        assert np.all(np.abs(a - b)[fin] <= 1e-12 * np.abs(a[fin]) + 1e-300)
+        finc = np.isfinite(ca)
+        assert np.all(np.abs(ca - cb)[finc] <= 1e-11 * np.abs(ca[finc]) + 1e-300)
+        y0, y1 = 16, 32
+        part = coracle.shade_f64(*[p[y0:y1] for p in planes], frame, dl, point_lights=pl, shadow=sh, y_offset=y0, full_height=h)
+        full = coracle.shade_f64(*planes, frame, dl, point_lights=pl, shadow=sh)
+        np.testing.assert_array_equal(part, full[y0:y1])
+        assert coracle.shade_f64(*planes, frame, dl).shape == (h, w, 4)
+
+
 def test_strip_equals_monolithic(coracle):
     gb, frame, dl, pl, sh = _scene(64, 48, 8, 64)
     planes = (gb['normal'], gb['albedo_occ'], gb['rough_metal'], gb['depth'])
