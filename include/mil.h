@@ -215,6 +215,22 @@ int mil_light_ex(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_dat
                  const mil_extras *extras, void *out, uint32_t out_pitch_px, mil_out_format fmt,
                  uint32_t flags, void *stream);
 
+/* NO COUNTERPART IN THE REFERENCE.  mil_light_ex for callers that cannot allocate: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same arguments, results bit-identical to mil_light_ex, except:
+ *   - extras->point_lights is a DEVICE pointer (n_point x mil_point_light, 16-byte aligned): the lights already live in
+ *     HBM; the prepared records the kernels read are derived by a small kernel on `stream`;
+ *   - n_point <= MIL_NOALLOC_MAX_POINT_LIGHTS, else MIL_ERR_CAPACITY (the context's own capacity does not apply);
+ *   - the staging buffer is a static __device__ array of the library (334 080 bytes per GPU, held until the process
+ *     ends) instead of the context's ring: the call enqueues at most two kernels on `stream` and calls no hipMalloc /
+ *     hipFree / hipMemcpy / event or stream routine.  Every call on one GPU shares that array: calls that OVERLAP on one
+ *     GPU (two streams, two threads, two contexts) race - serialise them.  The K2 launch order is the plain one (the
+ *     host never sees the lights); speed only. */
+#define MIL_NOALLOC_MAX_POINT_LIGHTS 4096u
+int mil_light_ex_noalloc(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                         const mil_directional_light *lights, const mil_push_constants *push,
+                         const mil_extras *extras, void *out, uint32_t out_pitch_px, mil_out_format fmt,
+                         uint32_t flags, void *stream);
+
 /* The hdr-writing subpasses that follow the lighting draw inside the reference's one render pass
  * (render/pbr/mod.rs:409-440), for mil_shade_frame.  NULL members switch a subpass off. */
 typedef struct mil_frame_passes {

@@ -415,6 +415,7 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
             if (hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming) != hipSuccess) rc = MIL_ERR_HIP;
     }
     if (rc == MIL_OK && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MIL_ERR_HIP;
+    if (rc == MIL_OK) rc = noalloc_init(c);      // the device address of the static scratch array of mil_light_ex_noalloc
     if (rc == MIL_OK) {
         uint8_t h[LUT11_N + LUT10_N];
         for (uint32_t i = 0; i < LUT11_N; i++) h[i] = srgb8(ufloat_dec(i, 6));
@@ -500,10 +501,10 @@ int mil_sync(mil_ctx *c, void *stream)
 // mil_light_ex, mil_shade_frame, mil_shade_bands: the same launch, the later ones with the later subpasses folded into the
 // store / the rows dealt in bands.  Every argument is validated before anything is staged or enqueued: an argument error
 // has no side effect.
-int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
-                   const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
-                   const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream,
-                   const mil_band_layout *bands, bool out_frame, const PreStaged *pre)
+int milhost::shade_check(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                         const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                         const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt,
+                         const mil_band_layout *bands, bool out_frame, const PreStaged *pre)
 {
     if (!c || !frame || !out) return MIL_ERR_BAD_ARG;
     if (passes && ((passes->accum != nullptr) != (passes->reveal != nullptr))) return MIL_ERR_BAD_ARG;
@@ -519,7 +520,19 @@ int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_dat
     if (sh && (!sh->map || sh->size == 0 || sh->size > 16384u)) return MIL_ERR_BAD_ARG;   // 32-bit texel offsets in the taps
     if (passes && passes->accum && (passes->accum_pitch_px < gb->width || passes->reveal_pitch_px < gb->width)) return MIL_ERR_BAD_ARG;
     if (out_frame && !bands) return MIL_ERR_BAD_ARG;
+    return MIL_OK;
+}
+
+int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
+                   const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *ex,
+                   const mil_frame_passes *passes, void *out, uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream,
+                   const mil_band_layout *bands, bool out_frame, const PreStaged *pre)
+{
+    int rc = shade_check(c, gb, frame, lights, push, ex, passes, out, out_pitch_px, fmt, bands, out_frame, pre);
+    if (rc) return rc;
     if ((rc = set_device(c))) return rc;
+    const uint32_t n_point = ex ? ex->n_point : 0;
+    const mil_shadow *sh = ex ? ex->shadow : nullptr;
 
     hipStream_t s = (hipStream_t)stream;
     const bool strict = (flags & MIL_FLAG_STRICT) != 0;

@@ -57,6 +57,7 @@ struct mil_ctx {
     uint32_t tonemap_rows = 0;   // K4 rows per lane            } tuning knobs: read from the environment only when
     uint32_t fxaa_rows = 2;      // K5 output rows per lane      } MIL_DEBUG=1 is set (mil_create); the defaults are what
     uint32_t k1_rows = 1;        // K1 pixels per lane           } the parity suite covers
+    uint8_t *static_scratch = nullptr;   // this device's copy of mil_noalloc.hip's __device__ array (hipGetSymbolAddress)
     int last_hip = 0;
 };
 
@@ -69,9 +70,17 @@ int set_device(mil_ctx *c);
 //   bands       NULL = the planes are a strip of contiguous rows
 //   out_frame   with bands: `out` is the assembled frame (rows of the whole frame) instead of the compacted local rows
 //   pre         NULL = stage the host light arrays through the ring; else they are already on the device
+//               (ex->point_lights is then a DEVICE pointer and is not read on the host)
+// shade_check is the argument validation alone (no side effect); shade runs it first.
+int shade_check(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_directional_light *lights,
+                const mil_push_constants *push, const mil_extras *ex, const mil_frame_passes *passes, void *out,
+                uint32_t out_pitch_px, mil_out_format fmt, const mil_band_layout *bands, bool out_frame, const PreStaged *pre);
 int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame, const mil_directional_light *lights,
           const mil_push_constants *push, const mil_extras *ex, const mil_frame_passes *passes, void *out,
           uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream, const mil_band_layout *bands,
           bool out_frame, const PreStaged *pre);
+
+// mil_noalloc.hip: per context at mil_create, with its device current: hipGetSymbolAddress of the static scratch array
+int noalloc_init(mil_ctx *c);
 
 } // namespace milhost

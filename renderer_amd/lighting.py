@@ -21,12 +21,14 @@ LIB_PATH = os.path.join(_HERE, 'libmil.so')
 OUT_HDR, OUT_LDR, OUT_SRGB8, OUT_SRGB8_VIA_LDR = 0, 1, 2, 3
 FLAG_STRICT, FLAG_NO_CULL, FLAG_SHADOW_LDS = 1, 2, 4
 TILE = 16
+NOALLOC_MAX_POINT_LIGHTS = 4096      # MIL_NOALLOC_MAX_POINT_LIGHTS
 
 EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'mil_destroy',
            'mil_set_tile_count_buffer', 'mil_set_tile_stamp_buffer', 'mil_sync', 'mil_light_directional', 'mil_tonemap',
            'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame',
            'mil_transparency_accumulate', 'mil_import_external_memory', 'mil_alloc_exportable_memory',
-           'mil_release_external_memory', 'mil_shade_bands', 'mil_band_local_rows', 'mil_row_weights']
+           'mil_release_external_memory', 'mil_shade_bands', 'mil_band_local_rows', 'mil_row_weights',
+           'mil_light_ex_noalloc']
 
 
 class MilError(RuntimeError):
@@ -104,6 +106,7 @@ def load_library(path=LIB_PATH):
                                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64)]
         lib.mil_release_external_memory.argtypes = [vp, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
+        lib.mil_light_ex_noalloc.argtypes = lib.mil_light_ex.argtypes
         lib.mil_shade_bands.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras),
                                         ctypes.POINTER(FramePasses), ctypes.POINTER(BandLayout), vp, u32, ctypes.c_int,
                                         ctypes.c_int, u32, vp]
@@ -319,6 +322,35 @@ class LightingPass:
             fp.accum, fp.reveal = accum.data_ptr(), reveal.data_ptr()
             fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
         return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream)
+
+    def light_ex_noalloc(self, gb, frame, lights, point_lights_dev=None, ambient=None, shadow=None, fmt=OUT_HDR, flags=0,
+                         out=None, stream=None):
+        """mil_light_ex_noalloc: mil_light_ex without any allocation inside the library (static device scratch).  The point
+        lights are a (n, 8) float32 CUDA tensor (they already live on the device); `out` should be given, so that nothing
+        allocates on this side of the ABI either."""
+        t = self.torch
+        h, w = gb['depth'].shape
+        lights = np.ascontiguousarray(lights if lights is not None else np.zeros((0, 8)), np.float32).reshape(-1, 8)
+        frame = np.ascontiguousarray(frame, np.float32).reshape(68)
+        push = self._push(gb, lights.shape[0])
+        ex = Extras()
+        if point_lights_dev is not None and point_lights_dev.shape[0]:
+            assert point_lights_dev.is_cuda and point_lights_dev.dtype == t.float32 and point_lights_dev.is_contiguous()
+            ex.point_lights, ex.n_point = point_lights_dev.data_ptr(), point_lights_dev.shape[0]
+        if ambient is not None:
+            ex.ambient = (ctypes.c_float * 3)(*[float(a) for a in ambient])
+        if shadow is not None:
+            sm = shadow['map']
+            sh = Shadow((ctypes.c_float * 16)(*[float(v) for v in shadow['light_view_proj']]), sm.data_ptr(), sm.shape[0], float(shadow['bias']))
+            ex.shadow = ctypes.pointer(sh)
+        if out is None:
+            out = (t.empty((h, w, 4), dtype=t.float32, device=self.device) if fmt == OUT_HDR
+                   else t.empty((h, w), dtype=t.int32, device=self.device))
+        pitch = out.stride(0) // 4 if fmt == OUT_HDR else out.stride(0)
+        g = self._gb(gb)
+        self._check(self.lib.mil_light_ex_noalloc(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
+                                                  ctypes.byref(ex), out.data_ptr(), pitch, fmt, flags, self._stream(stream)))
+        return out
 
     def shade_bands(self, gb, frame, lights, bands, point_lights=None, ambient=None, shadow=None, sky=None, accum=None,
                     reveal=None, fmt=OUT_LDR, flags=0, out=None, out_is_frame=False, stream=None):
