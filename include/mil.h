@@ -254,12 +254,14 @@ int mil_shade_frame(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     mil_out_format fmt, uint32_t flags, void *stream);
 
 /* Band dealing (SURVEY.md 8 e, multi-GPU strips): instead of one contiguous strip, a rank holds every n_ranks-th band
- * of band_rows rows of the frame, compacted: local row k of the planes is frame row
- *     ((k / band_rows) * n_ranks + rank) * band_rows + k % band_rows.
+ * of band_rows rows of the frame, compacted: row k of the planes is frame row
+ *     (((k / band_rows) + first_band) * n_ranks + rank) * band_rows + k % band_rows.
  * Dealt bands equalise the cost of the ranks without a calibration frame (a contiguous strip of the floor costs a
- * multiple of a strip of sky).  band_rows: a power of two >= 16 (a 16x16 tile never straddles two bands). */
+ * multiple of a strip of sky).  band_rows: a power of two >= 16 (a 16x16 tile never straddles two bands).
+ * first_band: the planes start at the rank's first_band-th band (0 = the rank's whole image; a launch over part of a
+ * rank's rows passes the sub-view's first band). */
 typedef struct mil_band_layout {
-    uint32_t band_rows, n_ranks, rank;
+    uint32_t band_rows, n_ranks, rank, first_band;
 } mil_band_layout;
 
 /* mil_shade_frame on a rank's dealt bands (no counterpart in the reference, which has one device: render/vulkan.rs:106-108).
@@ -271,7 +273,7 @@ int mil_shade_bands(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     const mil_directional_light *lights, const mil_push_constants *push, const mil_extras *extras,
                     const mil_frame_passes *passes, const mil_band_layout *bands, void *out, uint32_t out_pitch_px,
                     int out_is_frame, mil_out_format fmt, uint32_t flags, void *stream);
-/* Local rows rank `rank` holds of a frame of `height` rows under `bands` (host arithmetic only). */
+/* Local rows rank `rank` holds of a frame of `height` rows under `bands` (host arithmetic only; first_band ignored). */
 uint32_t mil_band_local_rows(const mil_band_layout *bands, uint32_t height);
 
 /* NEXT ROW, the HIP half of the Vulkan <-> HIP hand-over.  The reference's attachments are Vulkan
@@ -308,6 +310,67 @@ int mil_set_tile_stamp_buffer(mil_ctx *ctx, uint32_t *stamps, uint32_t n_tiles);
 int mil_row_weights(const mil_frame_matrix_data *frame, const mil_push_constants *push, uint32_t gb_height,
                     uint32_t y_offset, const mil_band_layout *bands, const mil_point_light *point_lights,
                     uint32_t n_point, uint32_t *weights);
+
+/* ---- Multi-GPU (SURVEY.md 8 b "Threading", 8 e): strips of one frame / one frame per GPU, gathered to GPU 0. ----
+ * No counterpart in the reference, which records the lighting draw for ONE device (render/mod.rs:189-219; the device is
+ * picked at render/vulkan.rs:106-108): these calls replace that draw for N devices.  A mil_mg owns, per rank it drives,
+ * one mil_ctx, a compute stream, a gather stream and an RCCL communicator.  The pass has no data-path exchange; the only
+ * communication is the gather, grouped ncclSend / ncclRecv to rank 0 (RCCL has no gather primitive), issued per CHUNK of a
+ * rank's rows on the gather stream behind an event, so it runs beside the shading of the next chunk.  The assembled frame
+ * equals the single-GPU frame bit for bit.  RCCL is bound at run time (dlopen librccl.so.1): MIL_ERR_RCCL if it is missing.
+ * One mil_mg = one thread at a time; calls enqueue and return, mil_mg_sync waits. */
+typedef struct mil_mg mil_mg;
+enum { MIL_MG_TRANSPORT_RCCL = 0,      /* grouped ncclSend / ncclRecv over xGMI */
+       MIL_MG_TRANSPORT_PEER_COPY = 1  /* hipMemcpyAsync device-to-device into GPU 0's image (one process only; the intra-node
+                                          alternative of SURVEY.md 8 e, and the way several ranks are rehearsed on one GPU) */ };
+enum { MIL_MG_FLAG_LOOPBACK = 1u       /* testing: rank 0 shades into its own `out` and sends to itself through the transport
+                                          instead of writing in place (exercises send / recv with a single GPU) */ };
+typedef struct mil_mg_config {
+    uint32_t max_point_lights;         /* capacity of every rank's context */
+    uint32_t band_rows;                /* strips: 0 = one contiguous strip per rank, cut on 16-row multiples; else the rows of a
+                                          band (power of two, 16..4096) dealt cyclically over the ranks (mil_band_layout) */
+    uint32_t chunks;                   /* launches per rank and frame (1..64, 0 = 4): gather of chunk k beside shading of k + 1 */
+    uint32_t transport, flags;
+} mil_mg_config;
+#define MIL_MG_UNIQUE_ID_BYTES 128
+
+/* One process driving n_devices GPUs (ncclCommInitAll); rank i = devices[i], rank 0 receives. */
+int mil_mg_create(mil_mg **out, int n_devices, const int *devices, const mil_mg_config *cfg);
+/* One process per GPU: rank 0 calls mil_mg_unique_id (ncclGetUniqueId), the host distributes the 128 bytes, every
+ * process calls mil_mg_create_rank (ncclCommInitRank; collective: returns when all ranks have called). */
+int mil_mg_unique_id(void *id);
+int mil_mg_create_rank(mil_mg **out, int world, int rank, int device, const void *id, const mil_mg_config *cfg);
+void mil_mg_destroy(mil_mg *mg);
+int mil_mg_world(const mil_mg *mg);
+int mil_mg_local_ranks(const mil_mg *mg);   /* ranks this process drives (io[] has that many entries, in rank order) */
+int mil_mg_rccl_ranks(const mil_mg *mg);    /* ncclCommCount of the communicator (0 with the peer-copy transport) */
+int mil_mg_last_rccl_error(const mil_mg *mg);
+int mil_mg_last_hip_error(const mil_mg *mg);
+/* The rows of a rank under cfg (host arithmetic, no GPU): how many, and which frame row each local row is. */
+uint32_t mil_mg_rows_of_rank(const mil_mg_config *cfg, int world, int rank, uint32_t height);
+int mil_mg_frame_rows_of_rank(const mil_mg_config *cfg, int world, int rank, uint32_t height, uint32_t *frame_rows);
+
+/* What one rank contributes; every pointer on that rank's device. */
+typedef struct mil_mg_rank_io {
+    mil_gbuffer gb;               /* the rank's rows of the planes, compacted (gb.height = mil_mg_rows_of_rank; y_offset ignored) */
+    const mil_extras *extras;     /* HOST struct (point lights HOST, shadow map on that device); may be NULL */
+    void *out;                    /* the rank's rows of the output, dense (out_pitch_px = width); rank 0 writes straight into the
+                                     destination instead (out may be NULL) unless MIL_MG_FLAG_LOOPBACK */
+    uint32_t out_pitch_px;
+} mil_mg_rank_io;
+
+/* ONE frame over all ranks (replaces render/mod.rs:201-216 + :297-309 for N devices): rank r shades its rows with
+ * mil_light_ex semantics (lighting fused with the encode of fmt) and the rows are gathered into `full` on rank 0's device
+ * (whole frame, dense; ignored by processes that do not drive rank 0).  push->resolution = the whole frame. */
+int mil_mg_render_strips(mil_mg *mg, const mil_mg_rank_io *io, const mil_frame_matrix_data *frame,
+                         const mil_directional_light *lights, const mil_push_constants *push, mil_out_format fmt,
+                         uint32_t flags, void *full, uint32_t full_pitch_px);
+/* ONE FRAME PER RANK (frame-parallel batches): frames[i] is the camera of local rank i, every rank shades a whole frame
+ * (its own planes, its own extras) and rank r's frame is gathered into slots[r] on rank 0's device (world pointers). */
+int mil_mg_render_frames(mil_mg *mg, const mil_mg_rank_io *io, const mil_frame_matrix_data *frames,
+                         const mil_directional_light *lights, const mil_push_constants *push, mil_out_format fmt,
+                         uint32_t flags, void *const *slots, uint32_t slot_pitch_px);
+int mil_mg_sync(mil_mg *mg);          /* waits for every local rank's compute and gather stream; reports async RCCL errors */
 
 int mil_sync(mil_ctx *ctx, void *stream);
 int mil_last_hip_error(const mil_ctx *ctx);

@@ -72,13 +72,13 @@ uint8_t srgb8(double c)
 bool bands_ok(const mil_band_layout *b)
 {
     return b->band_rows >= MIL_TILE && (b->band_rows & (b->band_rows - 1u)) == 0 && b->band_rows <= (1u << 20) &&
-           b->n_ranks >= 1 && b->n_ranks <= 4096 && b->rank < b->n_ranks;
+           b->n_ranks >= 1 && b->n_ranks <= 4096 && b->rank < b->n_ranks && b->first_band < (1u << 20);
 }
 // frame row of local row k (bands == NULL: a contiguous strip starting at y_offset)
 uint64_t frame_row(const mil_band_layout *b, uint32_t y_offset, uint32_t k)
 {
     if (!b) return (uint64_t)y_offset + k;
-    return ((uint64_t)(k / b->band_rows) * b->n_ranks + b->rank) * b->band_rows + k % b->band_rows;
+    return (((uint64_t)(k / b->band_rows) + b->first_band) * b->n_ranks + b->rank) * b->band_rows + k % b->band_rows;
 }
 
 int check_gbuffer(const mil_gbuffer *gb, const mil_push_constants *push, const mil_band_layout *bands)
@@ -235,12 +235,12 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
     memset(&p, 0, sizeof(p));
     p.normal = gb->normal_l_model; p.albedo = gb->albedo_occlusion; p.rm = gb->roughness_metallic; p.depth = gb->depth;
     p.width = gb->width; p.height = gb->height; p.pitch = gb->pitch_px; p.y_offset = gb->y_offset;
-    if (bands && bands->n_ranks > 1) {      // one rank: the dealing is the identity
+    if (bands) {
         uint32_t sh = 0;
         while ((1u << sh) < bands->band_rows) sh++;
         p.band_shift = sh;
-        p.band_extra = (bands->n_ranks - 1u) * bands->band_rows;
-        p.y_offset = bands->rank * bands->band_rows;
+        p.band_extra = (bands->n_ranks - 1u) * bands->band_rows;     // one rank: 0, the dealing is the identity
+        p.y_offset = (bands->first_band * bands->n_ranks + bands->rank) * bands->band_rows;
     }
     memcpy(p.inv_proj, f->inv_projection, 64);
     memcpy(p.inv_view, f->inv_view, 64);
@@ -261,7 +261,6 @@ void row_weights(const mil_frame_matrix_data *f, float res_y, uint32_t height, u
 {
     const uint32_t R = (height + MIL_TILE - 1) / MIL_TILE;
     for (uint32_t i = 0; i < R; i++) w[i] = 0;
-    if (bands && bands->n_ranks <= 1) bands = nullptr;
     const float *V = f->view, *P = f->projection;      // column-major
     const uint32_t tpb = bands ? bands->band_rows / MIL_TILE : 1;   // tile rows per band
     for (uint32_t i = 0; i < n_point; i++) {
@@ -295,8 +294,8 @@ void row_weights(const mil_frame_matrix_data *f, float res_y, uint32_t height, u
         } else {
             for (uint64_t g = g0; g <= g1; g++) {       // frame tile row g lies in band g / tpb
                 const uint64_t band = g / tpb;
-                if (band % bands->n_ranks != bands->rank) continue;
-                const uint64_t k = (band / bands->n_ranks) * tpb + g % tpb;
+                if (band % bands->n_ranks != bands->rank || band / bands->n_ranks < bands->first_band) continue;
+                const uint64_t k = (band / bands->n_ranks - bands->first_band) * tpb + g % tpb;
                 if (k < R) w[k]++;
             }
         }
@@ -306,7 +305,7 @@ void row_weights(const mil_frame_matrix_data *f, float res_y, uint32_t height, u
 // Scheduling heuristic of the tiled kernel (speed only; any permutation is correct): tile rows are launched
 // in descending order of the number of point lights whose bounding sphere can project onto them, ties from the
 // bottom of the frame upwards, so that the expensive rows are in flight early and the launch ends on cheap ones.
-struct RowOrderKey { float view[16], proj[16]; uint32_t height, y_offset, n_point, band_rows, n_ranks, rank; float res_y; uint64_t lights_gen; };
+struct RowOrderKey { float view[16], proj[16]; uint32_t height, y_offset, n_point, band_rows, n_ranks, rank, first_band; float res_y; uint64_t lights_gen; };
 void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_frame_matrix_data *f, const mil_band_layout *bands,
                 uint32_t gb_y_offset, const mil_point_light *pl, uint32_t n_point)
 {
@@ -317,7 +316,7 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     memset(&key, 0, sizeof(key));
     memcpy(key.view, f->view, 64); memcpy(key.proj, f->projection, 64);
     key.height = p.height; key.y_offset = gb_y_offset; key.n_point = n_point; key.res_y = p.res_y; key.lights_gen = lights ? lights->gen : 0;
-    if (bands) { key.band_rows = bands->band_rows; key.n_ranks = bands->n_ranks; key.rank = bands->rank; }
+    if (bands) { key.band_rows = bands->band_rows; key.n_ranks = bands->n_ranks; key.rank = bands->rank; key.first_band = bands->first_band; }
     static_assert(sizeof(c->row_key) >= sizeof(RowOrderKey), "row order key storage");
     if (c->row_key_valid && !memcmp(c->row_key, &key, sizeof(key))) {
         memcpy(p.row_order, c->row_order, sizeof(p.row_order));

@@ -58,7 +58,8 @@ class FramePasses(ctypes.Structure):      # mil_frame_passes
 
 
 class BandLayout(ctypes.Structure):        # mil_band_layout
-    _fields_ = [('band_rows', ctypes.c_uint32), ('n_ranks', ctypes.c_uint32), ('rank', ctypes.c_uint32)]
+    _fields_ = [('band_rows', ctypes.c_uint32), ('n_ranks', ctypes.c_uint32), ('rank', ctypes.c_uint32),
+                ('first_band', ctypes.c_uint32)]
 
 
 class TransparentFragments(ctypes.Structure):   # mil_transparent_fragments

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from renderer_amd import lighting, ubo
+from renderer_amd import lighting, multigpu, ubo
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -22,7 +22,7 @@ def declared_symbols():
 def test_header_symbols_are_exported():
     lib = lighting.load_library()
     syms = declared_symbols()
-    assert sorted(syms) == sorted(lighting.EXPORTS)
+    assert sorted(syms) == sorted(lighting.EXPORTS + multigpu.EXPORTS)
     for s in syms:
         assert hasattr(lib, s), s
     assert lib.mil_version() == 2
@@ -53,6 +53,25 @@ def test_calls_fail_loudly_without_gpu():
     h = ctypes.c_void_p()
     assert lib.mil_create(ctypes.byref(h), 0, 16) == -4 and not h.value
     assert lib.mil_create(None, 0, 16) == -1
+    with pytest.raises(lighting.MilError, match='-4'):                # the multi-GPU layer too
+        multigpu.MultiGpu.single_process([0])
+
+
+def test_multigpu_layout_arithmetic():
+    """mil_mg_frame_rows_of_rank (host arithmetic of the library): contiguous strips are sharding.strip_bounds (16-row cuts,
+    4320 -> 7 x 544 + 512), dealt bands are lighting.band_rows_of_rank; every frame row belongs to one rank."""
+    from renderer_amd import sharding
+    for height, world in [(4320, 8), (2160, 8), (2160, 3), (100, 8), (16, 4)]:
+        bounds = sharding.strip_bounds(height, world)
+        got = [multigpu.frame_rows_of_rank(height, world, r, band_rows=0) for r in range(world)]
+        for r, (y0, y1) in enumerate(bounds):
+            assert np.array_equal(got[r], np.arange(y0, y1)), (height, world, r)
+        for band in (16, 32, 128):
+            rows = [multigpu.frame_rows_of_rank(height, world, r, band_rows=band) for r in range(world)]
+            for r in range(world):
+                assert np.array_equal(rows[r], lighting.band_rows_of_rank(height, band, world, r))
+            assert np.array_equal(np.sort(np.concatenate(rows)), np.arange(height))
+    assert [len(multigpu.frame_rows_of_rank(4320, 8, r)) for r in range(8)] == [544] * 7 + [512]
 
 
 def test_product_does_not_import_the_oracle():
