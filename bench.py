@@ -4,17 +4,25 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path over one 3840x2160 synthetic G-buffer (Scene A, SURVEY.md
-8d): the lighting kernel (2 directional lights of main.rs:80-91, light 0 with 2048^2 3x3-PCF
-shadow, 256 point lights culled per 16x16 tile into LDS lists, ambient) writing the
-RGBA32F hdr attachment, then the fused tonemap/gamma kernel (ACES + sRGB8).  Inputs are
-resident in HBM before the timed region; three buffer sets (> 256 MiB) rotate so the
-Infinity Cache cannot hold a frame.  N > 1: frame-parallel (each rank shades its own frames
-of an orbiting camera; the frames are independent units and no data-path collective joins
-them); per-GPU work is fixed, so scaling is "weak".  The same loop is then timed once more
-with every packed frame gathered to GPU 0 by overlapped grouped P2P (north_star's
-presentation step; bound by one xGMI link per sender, 33 MB per frame) and reported beside
-`value` as config.gather_to_gpu0.  --mode strips always gathers (one frame is assembled).
+N = 1 (the configuration BASELINE.json's metric is quoted on): a step = one pass of the hot
+path over one 3840x2160 synthetic G-buffer (Scene A): the lighting kernel (2
+directional lights of main.rs:80-91, light 0 with 2048^2 3x3-PCF shadow, 256 point lights
+culled per 16x16 tile into LDS lists, ambient) writing the RGBA32F hdr attachment, then the
+tonemap/gamma kernel (ACES + sRGB8).  Inputs are resident in HBM before the timed region;
+three buffer sets (> 256 MiB) rotate so the Infinity Cache cannot hold a frame.
+
+N > 1 (north_star's multi-GPU claim): by default ONE 7680x4320 frame with 4096 point lights
+(BASELINE.json configs[3]) per step, cut over the ranks in dealt 32-row bands by libmil's
+multi-GPU layer (mil_mg_create_rank + mil_mg_render_strips: one process per GPU, RCCL
+communicator inside the library, grouped ncclSend / ncclRecv per chunk beside the shading of
+the next chunk) and ASSEMBLED ON GPU 0 inside the timed region: "scaling": "strong", `value`
+= frame pixels x steps / time with the gather included.  The same frame on rank 0 alone
+through the same code path is timed in the same run and reported as
+config.one_gpu_same_workload (the N = 1 default line is a different, smaller workload, so
+value(N) / value(1) across the two is NOT a scaling efficiency).  --mode frames: one 4K
+frame per rank per step (configs[4], "weak"), every frame gathered into its slot on GPU 0
+inside the timed region; the gather-free rate is reported beside it in config.
+--gather torch keeps the round-1 Python gather (torch.distributed batch_isend_irecv).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -47,13 +55,19 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='headline', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default=None, choices=sorted(WORKLOADS),
+                    help='default: headline at N = 1 and for --mode frames, cfg4_8k for N > 1 strips')
     ap.add_argument('--sets', type=int, default=3, help='rotating buffer sets (cold-cache protocol)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-extra', action='store_true', help='skip the 4K/1-light HBM-bound side measurement')
-    ap.add_argument('--mode', default='frames', choices=['frames', 'strips'],
-                    help='N > 1: frames = every rank shades whole frames (weak scaling); strips = one frame cut into '
-                         'horizontal strips on 16-row boundaries (strong scaling), both gathered to GPU 0')
+    ap.add_argument('--mode', default='strips', choices=['frames', 'strips'],
+                    help='N > 1: strips = one frame cut over the ranks (strong scaling, the default); frames = every rank '
+                         'shades a whole frame per step (weak scaling); both gathered to GPU 0 inside the timed region')
+    ap.add_argument('--gather', default='mil_mg', choices=['mil_mg', 'torch'],
+                    help='N > 1: mil_mg = the multi-GPU layer of libmil.so (RCCL inside the library); torch = the Python gather '
+                         '(torch.distributed P2P; the only choice for the one-GPU gloo rehearsal)')
+    ap.add_argument('--band-rows', type=int, default=32, help='mil_mg strips: rows per dealt band (0 = contiguous strips)')
+    ap.add_argument('--chunks', type=int, default=1, help='mil_mg: launches per rank and frame (1 = best throughput: frames are enqueued back to back and the gather of frame i hides under the shading of frame i + 1; 2 = lower single-frame latency)')
     ap.add_argument('--pipelined', action='store_true',
                     help='N = 1: tonemap of frame i on a second stream beside the lighting of frame i + 1 (+3 %%; off by default so '
                          'that per-kernel durations under rocprofv3 are those of kernels running alone)')
@@ -64,10 +78,12 @@ def parse():
     return ap.parse_args()
 
 
-def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64, rows=None, noise=False):
+def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64, rows=None, noise=False, all_lit=False):
     from renderer_amd import sharding
     w, h, n_dir, n_point, shadow_size, ambient = WORKLOADS[wl]
     cam = synth.sweep_camera(w, h) if frame_idx is None else sharding.orbit_camera(frame_idx, n_frames, w, h)
+    if all_lit:
+        cam = synth.all_lit_camera(w, h)
     gb0 = synth.scene_sweep(w, h, cam, device=device, rows=rows)       # rows: this rank's strip (global rows, y_offset set)
     if noise:        # Scene B: every plane i.i.d. random, every texel lit (nothing for an early-out to skip)
         gb0 = synth.scene_noise(w, h, 0x5EED0000, device=device)
@@ -287,6 +303,7 @@ def cpu_baseline(inp, target_s=12.0):
     sh = None if inp['sh'] is None else dict(inp['sh'], map=inp['sh']['map'].cpu().numpy())
 
     def run(rows, reps=1):
+        nonlocal threads
         y0 = h // 2 - rows // 2          # band through the sphere wall
         strip = {k: (v[y0:y0 + rows].cpu() if hasattr(v, 'cpu') else v) for k, v in inp['sets'][0].items()}
         g = synth.to_numpy(strip)
@@ -298,18 +315,184 @@ def cpu_baseline(inp, target_s=12.0):
             coracle.tonemap(hdr, 2, nthreads=threads)
         return time.perf_counter() - t0
 
-    rows = 16
-    t = run(rows)
-    rows_full = int(min(h, max(rows, rows * target_s / max(t, 1e-6)))) // 16 * 16
-    if rows_full > rows:
-        rows, t = rows_full, run(rows_full)
-    reps = 1
-    if t < target_s:                       # a whole frame is quicker than the sample budget: repeat it
-        reps = int(min(200, max(1, target_s / max(t, 1e-6))))
-        t = run(rows, reps)
-    return dict(value=round(reps * rows * w / t / 1e6, 4), unit='Mpix/s', cores=threads, kind='port',
-                sample=f'{reps} x {rows} of {h} rows x {w} px (band centred on the sphere wall), same lights/shadow/ambient, '
-                       f'lighting + tonemap, {t:.1f} s wall, oracle/mil_oracle.c brute-force over all lights, OpenMP')
+    def sample(budget_s):
+        rows = 16
+        t = run(rows)
+        rows_full = int(min(h, max(rows, rows * budget_s / max(t, 1e-6)))) // 16 * 16
+        if rows_full > rows:
+            rows, t = rows_full, run(rows_full)
+        reps = 1
+        if t < budget_s:                   # a whole frame is quicker than the sample budget: repeat it
+            reps = int(min(200, max(1, budget_s / max(t, 1e-6))))
+            t = run(rows, reps)
+        return reps, rows, t
+
+    all_threads = threads
+    reps, rows, t = sample(target_s)
+    res = dict(value=round(reps * rows * w / t / 1e6, 4), unit='Mpix/s', cores=all_threads, kind='port',
+               sample=f'{reps} x {rows} of {h} rows x {w} px (band centred on the sphere wall), same lights/shadow/ambient, '
+                      f'lighting + tonemap, {t:.1f} s wall, oracle/mil_oracle.c brute-force over all lights, OpenMP')
+    threads = 1                            # one thread beside all cores
+    reps, rows, t = sample(target_s / 2)
+    res['one_thread'] = dict(value=round(reps * rows * w / t / 1e6, 4), unit='Mpix/s', cores=1,
+                             sample=f'{reps} x {rows} rows x {w} px, {t:.1f} s wall, same band and lights')
+    return res
+
+
+def run_mg(args, torch, dist, world, rank, local_rank):
+    """N > 1 through libmil's multi-GPU layer (one process per GPU, RCCL inside the library).  Returns the result dict on
+    rank 0, None elsewhere."""
+    from renderer_amd import lighting, multigpu, sharding, synth, ubo
+    dev = f'cuda:{local_rank}'
+    strips = args.mode == 'strips'
+    wl = args.workload or ('cfg4_8k' if strips else 'headline')
+    w, h, n_dir, n_point, shadow_size, ambient = WORKLOADS[wl]
+    px = w * h
+    # the 128-byte RCCL id: made by rank 0 inside libmil (ncclGetUniqueId), carried by one torch.distributed broadcast
+    idt = torch.zeros(multigpu.UNIQUE_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        idt.copy_(torch.frombuffer(bytearray(multigpu.MultiGpu.unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    band_rows = args.band_rows if strips else 32
+    mg = multigpu.MultiGpu.per_process(world, rank, local_rank, idt.cpu().numpy().tobytes(), max_point_lights=4096,
+                                       band_rows=band_rows, chunks=args.chunks)
+    dl = ubo.default_directional_lights()[:n_dir]
+    base_pl = synth.point_light_field(n_point, 0x5EED0003) if n_point else None
+    sh = synth.shadow_setup(dl[0, 0:3], shadow_size, device=dev) if shadow_size else None
+    amb = (0.03, 0.03, 0.03) if ambient else None
+    n_sets = args.sets
+    if strips:
+        cam = synth.sweep_camera(w, h)
+        pl = base_pl
+        gb_full = synth.scene_sweep(w, h, cam, device=dev)
+        rows = torch.from_numpy(multigpu.frame_rows_of_rank(h, world, rank, band_rows=band_rows)).to(dev)
+        mine = {k: (v[rows].contiguous() if torch.is_tensor(v) else v) for k, v in gb_full.items()}
+        if rank != 0:
+            del gb_full
+    else:
+        cam = sharding.orbit_camera(rank, 64, w, h)
+        pl = sharding.animated_point_lights(base_pl, rank, 64) if base_pl is not None else None
+        mine = synth.scene_sweep(w, h, cam, device=dev)
+        gb_full = mine
+    frame = cam.frame_matrix_data()
+    lrows = mine['depth'].shape[0]
+    sets = [mine] + [{k: (v.clone() if torch.is_tensor(v) else v) for k, v in mine.items()} for _ in range(n_sets - 1)]
+    outs = [None if rank == 0 else torch.empty((lrows, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
+    parts = [[dict(gb=sets[s], point_lights=pl, ambient=amb, shadow=sh, out=outs[s])] for s in range(n_sets)]
+    fulls = slots = None
+    if rank == 0:
+        if strips:
+            fulls = [torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
+        else:
+            slots = [[torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(n_sets)]
+
+    def step(i):
+        s = i % n_sets
+        if strips:
+            mg.render_strips(parts[s], frame, dl, w, h, fmt=lighting.OUT_SRGB8, flags=args.flags, full=fulls[s] if rank == 0 else None)
+        else:
+            mg.render_frames(parts[s], [frame], dl, w, h, fmt=lighting.OUT_SRGB8, flags=args.flags, slots=slots[s] if rank == 0 else None)
+
+    def timed(fn, sync, steps, warmup, everyone=True):
+        for i in range(warmup):
+            fn(i)
+        sync()
+        if everyone:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(warmup + i)
+        sync()
+        if everyone:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if everyone:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
+    dt = timed(step, mg.sync, args.steps, args.warmup)
+    rccl_ranks = mg.rccl_ranks
+
+    # shading only, every rank for itself (no gather): what the transfer costs on top
+    lp = lighting.LightingPass(local_rank, max_point_lights=4096)
+    tmp = torch.empty((max(lrows, 1), w), dtype=torch.int32, device=dev)
+
+    def shade_only(i):
+        if lrows == 0:
+            return
+        gb = sets[i % n_sets]
+        if strips and band_rows:
+            lp.shade_bands(gb, frame, dl, (band_rows, world, rank, 0), pl, amb, sh, fmt=lighting.OUT_SRGB8, flags=args.flags, out=tmp)
+        elif strips:
+            lp.light_ex(dict(gb, y_offset=int(rows[0].item())), frame, dl, pl, amb, sh, fmt=lighting.OUT_SRGB8, flags=args.flags, out=tmp)
+        else:
+            lp.light_ex(gb, frame, dl, pl, amb, sh, fmt=lighting.OUT_SRGB8, flags=args.flags, out=tmp)
+    dt_shade = timed(shade_only, torch.cuda.synchronize, args.steps, args.warmup)
+
+    res = None
+    if rank == 0:
+        one = None
+        equal = None
+        if strips:
+            # the same frame on this GPU alone through the same code path (one rank: no transfer at all)
+            mg1 = multigpu.MultiGpu.single_process([local_rank], max_point_lights=4096, band_rows=band_rows, chunks=args.chunks,
+                                                   transport=multigpu.TRANSPORT_PEER_COPY)
+            full1 = torch.zeros((h, w), dtype=torch.int32, device=dev)
+            p1 = [dict(gb=gb_full, point_lights=pl, ambient=amb, shadow=sh, out=None)]
+            dt1 = timed(lambda i: mg1.render_strips(p1, frame, dl, w, h, fmt=lighting.OUT_SRGB8, flags=args.flags, full=full1),
+                        mg1.sync, max(5, args.steps // 2), 2, everyone=False)
+            n1 = max(5, args.steps // 2)
+            one = dict(value=round(n1 * px / dt1 / 1e6, 1), unit='Mpix/s', ms_per_step=round(dt1 / n1 * 1e3, 4),
+                       note='the whole frame on rank 0 alone, same library path (mil_mg with one rank), same run')
+            equal = bool(torch.equal(full1, fulls[(args.warmup + args.steps - 1) % n_sets]))
+            mg1.close()
+        total_px = px if strips else world * px
+        res = dict(metric='shaded Mpix/s at 3840x2160, 256 point lights + PCF shadows; % HBM/VALU roofline',
+                   value=round(args.steps * total_px / dt / 1e6, 1), unit='Mpix/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True, scaling=('strong' if strips else 'weak'),
+                   vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=f'{wl}: {w}x{h} Scene A sweep, {n_dir} directional (light 0 PCF {shadow_size}^2) + {n_point} point lights'
+                                        + (' + ambient' if amb else '') + ('' if strips else ', one frame per rank per step (orbiting camera, moving lights)'),
+                               kernels=['k_tiled + tonemap fused -> sRGB8 (mil_light_ex semantics inside mil_mg)'],
+                               parallelism=(f'{world} ranks, one process per GPU; ' +
+                                            (f'frame dealt in {band_rows}-row bands' if (strips and band_rows) else
+                                             ('contiguous 16-row-aligned strips' if strips else 'one frame per rank')) +
+                                            f', {args.chunks} chunks per rank, grouped ncclSend/ncclRecv to GPU 0 per chunk on a second stream'),
+                               gather='inside the timed region: `value` counts a frame when it is assembled on GPU 0',
+                               gather_path='libmil mil_mg (RCCL bound inside the library)', rccl_ranks=rccl_ranks,
+                               shading_only=dict(value=round(args.steps * total_px / dt_shade / 1e6, 1), unit='Mpix/s',
+                                                 ms_per_step=round(dt_shade / args.steps * 1e3, 4),
+                                                 note='every rank shading its rows with no transfer (max over ranks)'),
+                               buffer_sets=n_sets))
+        if one is not None:
+            res['config']['one_gpu_same_workload'] = one
+            res['config']['assembled_equals_single_gpu_bitwise'] = equal
+            res['config']['note'] = ('the N = 1 default line of this bench is BASELINE.json\'s metric configuration (4K, 256 lights, two kernels): '
+                                     'compare this value with config.one_gpu_same_workload, not with that line')
+        # roofline of the dominant kernel: the lighting launch over this rank's rows (k_tiled), HIP-event burst on its stream
+        if lrows:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(3):
+                shade_only(i)
+            torch.cuda.synchronize()
+            e0.record()
+            nb = max(args.steps, 10)
+            for i in range(nb):
+                shade_only(i)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / nb
+            abytes = lrows * w * 20 + 32 * (n_dir + n_point) + 272 + (shadow_size ** 2 * 4 if shadow_size else 0)
+            res['roofline'] = dict(bound='hbm', achieved=round(abytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                                   frac=round(abytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None, kernel='k_tiled (rank 0, its rows, fused sRGB8 store)',
+                                   ms=round(ms, 4), algorithmic_bytes=abytes,
+                                   note='at 4096 lights the kernel is VALU-bound: see the N = 1 run of --workload cfg4_8k for the FLOP fraction')
+    lp.close()
+    mg.close()
+    return res
 
 
 def main():
@@ -332,7 +515,8 @@ def main():
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_mg = os.environ.get('MIL_BENCH_FORCE_MG') == '1'       # smoke test of the mil_mg bench path with a world of one
+    if world > 1 or force_mg:
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group('gloo')
@@ -340,8 +524,18 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = f'cuda:{local_rank}'
 
+    if (world > 1 or force_mg) and args.gather == 'mil_mg' and not rehearse:
+        res = run_mg(args, torch, dist, world, rank, local_rank)
+        if rank == 0:
+            print(json.dumps(res))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if args.workload is None:
+        args.workload = 'cfg4_8k' if (world > 1 and args.mode == 'strips') else 'headline'
+
     lp = lighting.LightingPass(local_rank, max_point_lights=4096)
-    strips = args.mode == 'strips'
+    strips = args.mode == 'strips' and world > 1          # one GPU: the whole frame, nothing to cut
     if strips:
         from renderer_amd import sharding
         y0, y1 = sharding.strip_bounds(WORKLOADS[args.workload][1], world)[rank]
@@ -369,16 +563,13 @@ def main():
     px = inp['w'] * inp['h']
     pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if (inp['pl'] is not None and inp.get('lh', 1)) else 0
 
+    # N > 1: the gather to GPU 0 is inside the timed region (a frame counts when it is on GPU 0)
     dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
-                      pipelined=(args.pipelined and world == 1), gather=strips)
-    dt_gather = None
-    gather_error = None
-    if world > 1 and not strips:       # the same frames, each gathered to GPU 0 (xGMI-bound)
-        try:
-            dt_gather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
-                                     pipelined=False, gather=True)
-        except Exception as e:          # the headline measurement above must still be reported
-            gather_error = f'{type(e).__name__}: {e}'[:300]
+                      pipelined=(args.pipelined and world == 1), gather=True)
+    dt_nogather = None
+    if world > 1 and not strips:       # the same frames left on the GPUs that shaded them: what the transfer costs
+        dt_nogather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
+                                   pipelined=False, gather=False)
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -400,7 +591,9 @@ def main():
         if t:
             traffic = t['hbm_bytes_per_launch']
     roof_hbm = dict(bound='hbm', achieved=round(hbm, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm / HBM_PEAK_GBS, 4),
-                    traffic=traffic, kernel=kname, ms=round(light_ms, 4), algorithmic_bytes=abytes)
+                    traffic=traffic, traffic_source=(None if traffic is None else 'profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE '
+                                                     'passes of tools/profile_round.sh on this kernel and workload, committed; not measured in this run)'),
+                    kernel=kname, ms=round(light_ms, 4), algorithmic_bytes=abytes)
     roof_valu = dict(bound='valu', achieved=round(valu, 2), peak=VALU_PEAK_TFLOPS, unit='TFLOP/s',
                      frac=round(valu / VALU_PEAK_TFLOPS, 4), traffic=traffic, kernel=kname, ms=round(light_ms, 4),
                      algorithmic_flops=aflops, pairs_in_radius=pairs, lit_pixels=lit_px)
@@ -410,23 +603,25 @@ def main():
     res = dict(metric='shaded Mpix/s at 3840x2160, 256 point lights + PCF shadows; % HBM/VALU roofline',
                value=round((1 if strips else world) * args.steps * px / dt / 1e6, 1), unit='Mpix/s', n_gpus=world, steps=args.steps,
                warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+               lit_mpix_s=round((1 if strips else world) * args.steps * lit_px / dt / 1e6, 1),
                scaling=('strong' if strips else 'weak'),
                vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload=f'{args.workload}: {inp["w"]}x{inp["h"]} Scene A sweep, {inp["n_dir"]} directional '
                                     f'(light 0 PCF {inp["shadow_size"]}^2) + {inp["n_point"]} point lights'
                                     + (' + ambient' if inp['amb'] else ''),
                            kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
-                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned{", cost-weighted " + str([b - a for a, b in inp["bounds"]]) if inp.get("bounds") else ""}) + P2P gather to GPU 0' if strips else f'frame-parallel x{world}, frames stay on their GPUs')),
+                           buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned{", cost-weighted " + str([b - a for a, b in inp["bounds"]]) if inp.get("bounds") else ""}) + P2P gather to GPU 0' if strips else f'frame-parallel x{world}, every frame gathered to GPU 0 inside the timed region')),
                            tonemap_ms=round(tone_burst_ms, 4),
                            streams=('1 (serial)' if (not args.pipelined or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),
                roofline=primary, roofline_other=other)
-    if gather_error is not None:
-        res['config']['gather_to_gpu0'] = dict(error=gather_error)
-    if dt_gather is not None:
-        res['config']['gather_to_gpu0'] = dict(value=round(world * args.steps * px / dt_gather / 1e6, 1), unit='Mpix/s',
-                                               ms_per_step=round(dt_gather / args.steps * 1e3, 4),
-                                               note='same loop with every packed sRGB8 frame (33.2 MB) sent to GPU 0 by grouped P2P over xGMI')
+    if world > 1:
+        res['config']['gather'] = 'inside the timed region: `value` counts a frame when it is on GPU 0'
+        res['config']['gather_path'] = 'torch.distributed batch_isend_irecv (' + ('gloo rehearsal on one GPU: the numbers mean nothing' if rehearse else 'nccl = RCCL') + ')'
+    if dt_nogather is not None:
+        res['config']['shading_only'] = dict(value=round(world * args.steps * px / dt_nogather / 1e6, 1), unit='Mpix/s',
+                                             ms_per_step=round(dt_nogather / args.steps * 1e3, 4),
+                                             note='same loop with every frame left on the GPU that shaded it')
 
     if not args.no_extra and world == 1 and args.workload == 'headline':
         # side measurement: the HBM-bound 4K / 1-light lighting pass (BASELINE.md target >= 70 % of HBM roofline)
@@ -444,6 +639,18 @@ def main():
                                                     hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                                     note='tools/probe/stream_probe.hip: the same four-plane access pattern with no arithmetic takes 43.6 us (6.09 TB/s), a float4 copy 41.6 us')
         del inp1
+        # side measurement: the headline step on an ALL-LIT view of the same scene (camera pitched onto floor + spheres: no texel
+        # keeps the cleared G-buffer, so nothing is skipped by the occlusion-0 early-out that covers 49 % of the headline frame)
+        inpl = build_inputs(torch, synth, ubo, 'headline', dev, args.sets, all_lit=True)
+        dtl = run_workload(torch, lighting, lp, inpl, args.steps, args.warmup, False, args.flags, pipelined=False)
+        ll = kernel_burst(torch, lighting, lp, inpl, max(args.steps, 20), False, args.flags)
+        pairs_l = lp.count_pairs(inpl['sets'][0], inpl['frame'], inpl['pl'])
+        bl, fl = algorithmic(inpl, pairs_l, False, px)
+        res['extra']['headline_all_lit'] = dict(value=round(args.steps * px / dtl / 1e6, 1), unit='Mpix/s', ms_per_step=round(dtl / args.steps * 1e3, 4),
+                                                k_tiled_ms=round(ll, 4), lit_pixels=px, pairs_in_radius=pairs_l,
+                                                hbm_frac=round(bl / ll / 1e6 / HBM_PEAK_GBS, 4), valu_frac=round(fl / ll / 1e9 / VALU_PEAK_TFLOPS, 4),
+                                                note='same lights, shadow, ambient and two-kernel step as `value`; camera (7, 9, 4.5) pitched 63 degrees down')
+        del inpl
         # side measurement: lighting + tonemap as ONE launch (hdr stays in registers; what mil_shade_frame does when the frame has
         # no sky / transparency subpass): same output as the two-kernel step that `value` times
         if not args.fused:

@@ -329,7 +329,10 @@ typedef struct mil_mg_config {
     uint32_t max_point_lights;         /* capacity of every rank's context */
     uint32_t band_rows;                /* strips: 0 = one contiguous strip per rank, cut on 16-row multiples; else the rows of a
                                           band (power of two, 16..4096) dealt cyclically over the ranks (mil_band_layout) */
-    uint32_t chunks;                   /* launches per rank and frame (1..64, 0 = 4): gather of chunk k beside shading of k + 1 */
+    uint32_t chunks;                   /* launches per rank and frame (1..64, 0 = 4): the gather of chunk k runs beside the shading of
+                                          chunk k + 1 (chunk 0 on a higher-priority stream).  1 = best throughput when frames are
+                                          enqueued back to back (the gather of frame i then hides under frame i + 1); 2 = lower
+                                          latency of a single frame; more chunks cost more than they hide */
     uint32_t transport, flags;
 } mil_mg_config;
 #define MIL_MG_UNIQUE_ID_BYTES 128

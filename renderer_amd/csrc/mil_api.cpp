@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "mil_internal.h"
 
@@ -256,13 +257,22 @@ void fill_common(mil::ShadeParams &p, const mil_gbuffer *gb, const mil_frame_mat
 
 // Scheduling weight of the local tile rows of a launch: w[i] = number of point lights whose bounding sphere can project
 // onto local tile row i.  Lights behind the camera weigh nothing; a sphere the near plane cuts counts for every row.
+// O(n_point + tile rows): every light adds +1 / -1 at the ends of its range of FRAME tile rows, a prefix sum gives the
+// frame's weights, and the launch's local rows pick theirs.
 void row_weights(const mil_frame_matrix_data *f, float res_y, uint32_t height, uint32_t y_offset, const mil_band_layout *bands,
                  const mil_point_light *pl, uint32_t n_point, uint32_t *w)
 {
     const uint32_t R = (height + MIL_TILE - 1) / MIL_TILE;
     for (uint32_t i = 0; i < R; i++) w[i] = 0;
+    if (!(res_y >= 1.0f) || res_y > 16777216.0f) return;
+    // frame rows are counted from the launch's first frame row onwards in units of 16 rows: a strip may start on any row,
+    // so its local tile row i covers frame rows y_offset + 16 i .. + 15
+    const double base = bands ? 0.0 : (double)y_offset;
+    const uint32_t FR = (uint32_t)(((double)res_y - base + MIL_TILE - 1) / MIL_TILE) + 1;     // tile rows from `base` to the frame's end
+    if (FR > (1u << 21)) return;
+    static thread_local std::vector<int32_t> diff;
+    diff.assign(FR + 1, 0);
     const float *V = f->view, *P = f->projection;      // column-major
-    const uint32_t tpb = bands ? bands->band_rows / MIL_TILE : 1;   // tile rows per band
     for (uint32_t i = 0; i < n_point; i++) {
         const float *c = pl[i].position;
         const double r = pl[i].radius;
@@ -283,21 +293,21 @@ void row_weights(const mil_frame_matrix_data *f, float res_y, uint32_t height, u
             }
         }
         if (!(lo == lo) || !(hi == hi)) { lo = -1.0; hi = 1.0; }
-        const double y0 = (lo * 0.5 + 0.5) * res_y, y1 = (hi * 0.5 + 0.5) * res_y;      // frame rows
-        if (y1 < 0.0 || y0 >= (double)res_y) continue;
-        const uint64_t g0 = y0 <= 0.0 ? 0u : (uint64_t)(y0 / MIL_TILE), g1 = (uint64_t)((y1 >= (double)res_y ? (double)res_y - 1.0 : y1) / MIL_TILE);
-        if (!bands) {                                   // local tile row = frame tile row - y_offset / 16 (strips start on any row)
-            const double l0 = y0 - (double)y_offset, l1 = y1 - (double)y_offset;
-            if (l1 < 0.0 || l0 >= (double)height) continue;
-            const uint32_t r0 = l0 <= 0.0 ? 0u : (uint32_t)(l0 / MIL_TILE), r1 = l1 >= (double)height ? R - 1 : (uint32_t)(l1 / MIL_TILE);
-            for (uint32_t k = r0; k <= r1 && k < R; k++) w[k]++;
-        } else {
-            for (uint64_t g = g0; g <= g1; g++) {       // frame tile row g lies in band g / tpb
-                const uint64_t band = g / tpb;
-                if (band % bands->n_ranks != bands->rank || band / bands->n_ranks < bands->first_band) continue;
-                const uint64_t k = (band / bands->n_ranks - bands->first_band) * tpb + g % tpb;
-                if (k < R) w[k]++;
-            }
+        const double y0 = (lo * 0.5 + 0.5) * res_y - base, y1 = (hi * 0.5 + 0.5) * res_y - base;      // rows from `base`
+        if (y1 < 0.0 || y0 >= (double)res_y - base) continue;
+        const uint32_t g0 = y0 <= 0.0 ? 0u : (uint32_t)(y0 / MIL_TILE);
+        const uint32_t g1 = y1 >= (double)res_y - base ? FR - 1 : (uint32_t)(y1 / MIL_TILE);
+        diff[g0] += 1;
+        diff[(g1 < FR ? g1 : FR - 1) + 1] -= 1;
+    }
+    for (uint32_t g = 1; g <= FR; g++) diff[g] += diff[g - 1];
+    if (!bands) {
+        for (uint32_t k = 0; k < R && k < FR; k++) w[k] = (uint32_t)diff[k];
+    } else {
+        const uint32_t tpb = bands->band_rows / MIL_TILE;   // tile rows per band
+        for (uint32_t k = 0; k < R; k++) {                  // local tile row k lies in the rank's band k / tpb + first_band
+            const uint64_t g = (((uint64_t)(k / tpb) + bands->first_band) * bands->n_ranks + bands->rank) * tpb + k % tpb;
+            if (g < FR) w[k] = (uint32_t)diff[g];
         }
     }
 }
@@ -317,11 +327,13 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     memcpy(key.view, f->view, 64); memcpy(key.proj, f->projection, 64);
     key.height = p.height; key.y_offset = gb_y_offset; key.n_point = n_point; key.res_y = p.res_y; key.lights_gen = lights ? lights->gen : 0;
     if (bands) { key.band_rows = bands->band_rows; key.n_ranks = bands->n_ranks; key.rank = bands->rank; key.first_band = bands->first_band; }
-    static_assert(sizeof(c->row_key) >= sizeof(RowOrderKey), "row order key storage");
-    if (c->row_key_valid && !memcmp(c->row_key, &key, sizeof(key))) {
-        memcpy(p.row_order, c->row_order, sizeof(p.row_order));
-        return;
-    }
+    static_assert(sizeof(c->row_cache[0].key) >= sizeof(RowOrderKey), "row order key storage");
+    // a frame is often shaded in several launches (chunks of a rank's rows, strips): a few orders are kept side by side
+    for (int e = 0; e < ROW_ORDER_CACHE; e++)
+        if (c->row_cache[e].valid && !memcmp(c->row_cache[e].key, &key, sizeof(key))) {
+            memcpy(p.row_order, c->row_cache[e].order, sizeof(p.row_order));
+            return;
+        }
     uint32_t w[MIL_MAX_ROW_ORDER];
     row_weights(f, p.res_y, p.height, gb_y_offset, bands, pl, n_point, w);
     // stable counting order: weight descending, then row index descending (bottom first)
@@ -331,9 +343,12 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     for (uint32_t lvl = wmax + 1; lvl-- > 0;)
         for (uint32_t i = R; i-- > 0;)
             if (w[i] == lvl) p.row_order[n++] = (uint16_t)i;
-    memcpy(c->row_order, p.row_order, sizeof(p.row_order));
-    memcpy(c->row_key, &key, sizeof(key));
-    c->row_key_valid = true;
+    RowOrderEntry &slot = c->row_cache[c->row_cache_next];
+    c->row_cache_next = (c->row_cache_next + 1) % ROW_ORDER_CACHE;
+    memcpy(slot.order, p.row_order, sizeof(p.row_order));
+    memset(slot.key, 0, sizeof(slot.key));
+    memcpy(slot.key, &key, sizeof(key));
+    slot.valid = true;
 }
 
 // A launch was issued (status `launch`); remember on which stream the slot's content is being read.

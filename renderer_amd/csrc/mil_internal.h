@@ -29,6 +29,13 @@ struct Slot {
     uint64_t gen = 0;            // bumped whenever new content is staged into this slot
 };
 
+constexpr int ROW_ORDER_CACHE = 16;
+struct RowOrderEntry {
+    uint16_t order[MIL_MAX_ROW_ORDER];
+    uint8_t key[192];
+    bool valid = false;
+};
+
 // Light arrays that already lie in device memory in the slot layout (prepared there by a kernel on the caller's stream):
 // nothing is staged, recorded or waited for.
 struct PreStaged {
@@ -51,9 +58,8 @@ struct mil_ctx {
     uint32_t *tile_counts = nullptr, *tile_stamps = nullptr;
     uint32_t tile_counts_cap = 0, tile_stamps_cap = 0;   // tiles the diagnostic buffers hold
     uint32_t tune = 0;
-    uint16_t row_order[MIL_MAX_ROW_ORDER];   // last computed K2 row order and what it was computed from (order_rows)
-    uint8_t row_key[192];
-    bool row_key_valid = false;
+    milhost::RowOrderEntry row_cache[milhost::ROW_ORDER_CACHE];   // recent K2 row orders and what each was computed from (order_rows)
+    int row_cache_next = 0;
     uint32_t tonemap_rows = 0;   // K4 rows per lane            } tuning knobs: read from the environment only when
     uint32_t fxaa_rows = 2;      // K5 output rows per lane      } MIL_DEBUG=1 is set (mil_create); the defaults are what
     uint32_t k1_rows = 1;        // K1 pixels per lane           } the parity suite covers

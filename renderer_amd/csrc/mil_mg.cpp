@@ -68,7 +68,7 @@ struct Piece { uint32_t local0, rows, frame0; };
 struct Local {                      // one rank this process drives
     int rank = 0, device = 0;
     mil_ctx *ctx = nullptr;
-    hipStream_t compute = nullptr, gather = nullptr;
+    hipStream_t compute = nullptr, compute_first = nullptr, gather = nullptr;   // compute_first: higher priority, chunk 0 of a frame
     ncclComm_t comm = nullptr;
     std::vector<hipEvent_t> chunk_done;      // compute -> gather, one per chunk
     hipEvent_t gathered = nullptr;           // gather stream: the rank's previous frame has left its output buffer
@@ -155,7 +155,14 @@ int create_common(mil_mg *m, const mil_mg_config *cfg)
         int rc = mil_create(&l.ctx, l.device, cfg->max_point_lights);
         if (rc) return rc;
         MG_HIP(m, hipSetDevice(l.device));
-        MG_HIP(m, hipStreamCreateWithFlags(&l.compute, hipStreamNonBlocking));
+        // The first chunk of a frame runs on a higher-priority stream beside the rest of the frame on the other: the GPU hands
+        // its workgroups out first, so the chunk finishes (and its gather starts) early, and the rest fills the slots its tail
+        // leaves idle - two launches one after the other on ONE stream pay the tail of heavy tiles twice (8K / 4096 lights,
+        // one eighth of the frame: 405 us as one launch, 553 as two on one stream, 461 as two on prioritised streams).
+        int least = 0, greatest = 0;
+        MG_HIP(m, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        MG_HIP(m, hipStreamCreateWithPriority(&l.compute, hipStreamNonBlocking, least));
+        MG_HIP(m, hipStreamCreateWithPriority(&l.compute_first, hipStreamNonBlocking, greatest));
         MG_HIP(m, hipStreamCreateWithFlags(&l.gather, hipStreamNonBlocking));
         MG_HIP(m, hipEventCreateWithFlags(&l.gathered, hipEventDisableTiming));
         const uint32_t n = cfg->chunks ? cfg->chunks : 4u;
@@ -218,6 +225,7 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
         if (l.gathered_valid) {
             MG_HIP(m, hipSetDevice(l.device));
             MG_HIP(m, hipStreamWaitEvent(l.compute, l.gathered, 0));
+            MG_HIP(m, hipStreamWaitEvent(l.compute_first, l.gathered, 0));
         }
     const size_t row_bytes = (size_t)push->resolution[0] * bpp;
     for (size_t c = 0; c < n_chunks; c++) {
@@ -235,21 +243,22 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
             const mil_frame_matrix_data *f = per_rank_frame ? &frames[i] : frames;
             const uint32_t out_pitch = in_place[i] ? dst_pitch_px : r.out_pitch_px;
             int rc;
+            hipStream_t cs = (c == 0 && n_chunks > 1) ? l.compute_first : l.compute;
             if (strips && m->cfg.band_rows) {
                 const mil_band_layout b = { m->cfg.band_rows, (uint32_t)m->world, (uint32_t)l.rank, k0 / m->cfg.band_rows };
                 gb.y_offset = 0;
                 void *out = in_place[i] ? dst_of[0] : (void *)((uint8_t *)r.out + (size_t)k0 * out_pitch * bpp);
-                rc = shade(l.ctx, &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, l.compute, &b, in_place[i], nullptr);
+                rc = shade(l.ctx, &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, cs, &b, in_place[i], nullptr);
             } else {
                 const uint32_t y0 = pl.pieces[0].frame0 + k0;      // contiguous rows: one piece
                 gb.y_offset = y0;
                 void *out = in_place[i] ? (void *)((uint8_t *)dst_of[0] + (size_t)(strips ? y0 : k0) * out_pitch * bpp)
                                         : (void *)((uint8_t *)r.out + (size_t)k0 * out_pitch * bpp);
-                rc = shade(l.ctx, &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, l.compute, nullptr, false, nullptr);
+                rc = shade(l.ctx, &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, cs, nullptr, false, nullptr);
             }
             if (rc) return rc;
             MG_HIP(m, hipSetDevice(l.device));
-            MG_HIP(m, hipEventRecord(l.chunk_done[c], l.compute));
+            MG_HIP(m, hipEventRecord(l.chunk_done[c], cs));
             MG_HIP(m, hipStreamWaitEvent(l.gather, l.chunk_done[c], 0));
         }
         // gather chunk c: senders -> rank 0.  One group holds every send and receive of this process (RCCL requires that of a
@@ -314,6 +323,7 @@ void mil_mg_destroy(mil_mg *m)
     for (Local &l : m->locals) {
         (void)hipSetDevice(l.device);
         if (l.compute) (void)hipStreamSynchronize(l.compute);
+        if (l.compute_first) (void)hipStreamSynchronize(l.compute_first);
         if (l.gather) (void)hipStreamSynchronize(l.gather);
     }
     for (Local &l : m->locals) {
@@ -322,6 +332,7 @@ void mil_mg_destroy(mil_mg *m)
         for (hipEvent_t e : l.chunk_done) if (e) (void)hipEventDestroy(e);
         if (l.gathered) (void)hipEventDestroy(l.gathered);
         if (l.compute) (void)hipStreamDestroy(l.compute);
+        if (l.compute_first) (void)hipStreamDestroy(l.compute_first);
         if (l.gather) (void)hipStreamDestroy(l.gather);
         if (l.ctx) mil_destroy(l.ctx);
     }
@@ -443,6 +454,7 @@ int mil_mg_sync(mil_mg *m)
     for (Local &l : m->locals) {
         MG_HIP(m, hipSetDevice(l.device));
         MG_HIP(m, hipStreamSynchronize(l.compute));
+        MG_HIP(m, hipStreamSynchronize(l.compute_first));
         MG_HIP(m, hipStreamSynchronize(l.gather));
         if (l.comm && rccl().ok) {
             ncclResult_t ae = ncclSuccess;

@@ -356,7 +356,7 @@ class LightingPass:
     def shade_bands(self, gb, frame, lights, bands, point_lights=None, ambient=None, shadow=None, sky=None, accum=None,
                     reveal=None, fmt=OUT_LDR, flags=0, out=None, out_is_frame=False, stream=None):
         """mil_shade_bands: mil_shade_frame on a rank's dealt bands.  gb: the rank's compacted planes with width / height
-        of the WHOLE frame in gb['width'] / gb['height']; bands = (band_rows, n_ranks, rank).  out: the rank's compacted
+        of the WHOLE frame in gb['width'] / gb['height']; bands = (band_rows, n_ranks, rank[, first_band]).  out: the rank's compacted
         output, or (out_is_frame) the assembled frame."""
         t = self.torch
         fp = FramePasses()
@@ -370,7 +370,7 @@ class LightingPass:
             fp.accum, fp.reveal = accum.data_ptr(), reveal.data_ptr()
             fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
         return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream,
-                           bands=BandLayout(*bands), out_is_frame=out_is_frame)
+                           bands=BandLayout(*(tuple(bands) + (0,) * (4 - len(bands)))), out_is_frame=out_is_frame)
 
     def _shade(self, gb, frame, lights, point_lights, ambient, shadow, passes, fmt, flags, out, stream, bands=None,
                out_is_frame=False):

@@ -30,6 +30,14 @@ def sweep_camera(width, height):
                                  fov_deg=90.0, aspect_ratio=width / height, near=0.05, far=100.0)
 
 
+def all_lit_camera(width, height):
+    """The same scene seen from above the sphere wall, pitched 63 degrees down: every pixel hits the floor or a sphere
+    (12 % spheres), so no texel keeps the cleared G-buffer and nothing is skipped by an occlusion-0 early-out."""
+    f = np.array([-0.5, -1.0, 0.0])
+    return ubo.PerspectiveCamera(position=(7.0, 9.0, 4.5), forward=tuple(f / np.linalg.norm(f)), up=(0.0, -1.0, 0.0),
+                                 fov_deg=90.0, aspect_ratio=width / height, near=0.05, far=100.0)
+
+
 def _as_i32(v):
     """int64 holding a u32 bit pattern -> int32 with the same bits."""
     v = v & 0xFFFFFFFF
