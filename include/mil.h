@@ -297,6 +297,16 @@ int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     const mil_push_constants *push, const mil_point_light *point_lights, uint32_t n_point,
                     unsigned long long *count, void *stream);
 
+/* Tuning.  Fast-mode mil_light_ex launches with at least min_point_lights point lights take the two-kernel form
+ * (k_bin: classification + two-level culling into per-half-tile lists and cost buckets; k_shade: one wave per listed half
+ * tile, most expensive first), the others the one-kernel form (k_tiled); results are bit-identical.  Default
+ * MIL_TWO_KERNEL_DEFAULT (measured crossover on a 4K frame); 1 = always, 0xFFFFFFFF = never.  The two-kernel form keeps a
+ * workspace sized for the largest frame shaded so far: like the reference, which recreates its attachments on resize
+ * (render/pbr/mod.rs:263-346), a LARGER frame reallocates it (hipFree + hipMalloc: waits for the device); mil_create
+ * reserves a 3840 x 2160 frame.  One workspace per context: launches of one context on different streams are serialised. */
+#define MIL_TWO_KERNEL_DEFAULT 1024u
+int mil_set_two_kernel_threshold(mil_ctx *ctx, uint32_t min_point_lights);
+
 /* After a culled mil_light_ex: per-tile light-list lengths of that call are written to
  * `counts` (DEVICE, n_tiles uint32) when set before the call; NULL disables.  A launch with more than n_tiles
  * tiles (tiles_x * tiles_y) leaves the buffer untouched. */
@@ -330,9 +340,9 @@ typedef struct mil_mg_config {
     uint32_t band_rows;                /* strips: 0 = one contiguous strip per rank, cut on 16-row multiples; else the rows of a
                                           band (power of two, 16..4096) dealt cyclically over the ranks (mil_band_layout) */
     uint32_t chunks;                   /* launches per rank and frame (1..64, 0 = 4): the gather of chunk k runs beside the shading of
-                                          chunk k + 1 (chunk 0 on a higher-priority stream).  1 = best throughput when frames are
-                                          enqueued back to back (the gather of frame i then hides under frame i + 1); 2 = lower
-                                          latency of a single frame; more chunks cost more than they hide */
+                                          chunk k + 1.  1 = best throughput when frames are enqueued back to back (the gather of frame
+                                          i then hides under frame i + 1); 2 = lower latency of a single frame; every launch pays the
+                                          tail of its heaviest tiles, so more chunks cost more than they hide */
     uint32_t transport, flags;
 } mil_mg_config;
 #define MIL_MG_UNIQUE_ID_BYTES 128

@@ -351,6 +351,33 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     slot.valid = true;
 }
 
+// Make the workspace hold `items` half tiles (TileWorkspace, mil_internal.h).  Grows only; growing waits for the device.
+int workspace_reserve(mil_ctx *c, uint32_t tiles_x, uint32_t tiles_y)
+{
+    TileWorkspace &w = c->ws;
+    const uint32_t items = 2u * tiles_x * tiles_y;
+    // a shard's segment holds the half tiles of its tiles: every MIL_WS_SHARDS-th tile, two each
+    const uint32_t seg = ((tiles_x * tiles_y + MIL_WS_SHARDS - 1u) / MIL_WS_SHARDS) * 2u;
+    if (items <= w.items_cap && seg <= w.seg_cap) return MIL_OK;
+    if (w.base) { HIP_TRY(c, hipFree(w.base)); w.base = nullptr; w.items_cap = 0; w.seg_cap = 0; }      // hipFree waits for the kernels that use it
+    const uint32_t stride = c->max_point < MIL_WS_LIST_MAX ? ((c->max_point + 63u) & ~63u) : MIL_WS_LIST_MAX;
+    const size_t counts_b = (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4 + 256;
+    const size_t items_b = ((size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * seg * 4 + 255) & ~(size_t)255;
+    const size_t order_b = ((size_t)items * 4 + 255) & ~(size_t)255, meta_b = order_b;
+    const size_t lists_b = (size_t)items * (stride ? stride : 64u) * 2;
+    HIP_TRY(c, hipMalloc((void **)&w.base, counts_b + items_b + order_b + meta_b + lists_b));
+    w.shard_count = (uint32_t *)w.base;
+    w.total = (uint32_t *)(w.base + (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4);
+    w.shard_items = (uint32_t *)(w.base + counts_b);
+    w.order = (uint32_t *)(w.base + counts_b + items_b);
+    w.meta = (uint32_t *)(w.base + counts_b + items_b + order_b);
+    w.lists = (uint16_t *)(w.base + counts_b + items_b + order_b + meta_b);
+    w.items_cap = items; w.list_stride_max = stride ? stride : 64u; w.seg_cap = seg;
+    w.used = false;
+    if (!w.done) HIP_TRY(c, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+    return MIL_OK;
+}
+
 // A launch was issued (status `launch`); remember on which stream the slot's content is being read.
 int finish(mil_ctx *c, Slot *sl, hipStream_t s, hipError_t launch)
 {
@@ -429,6 +456,7 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
             if (hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming) != hipSuccess) rc = MIL_ERR_HIP;
     }
     if (rc == MIL_OK && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MIL_ERR_HIP;
+    if (rc == MIL_OK && max_point_lights) rc = workspace_reserve(c, 240u, 135u);      // a 3840 x 2160 frame's tiles
     if (rc == MIL_OK) rc = noalloc_init(c);      // the device address of the static scratch array of mil_light_ex_noalloc
     if (rc == MIL_OK) {
         uint8_t h[LUT11_N + LUT10_N];
@@ -460,6 +488,8 @@ void mil_destroy(mil_ctx *c)
         if (s.dev) (void)hipFree(s.dev);
     }
     if (c->lut) (void)hipFree(c->lut);
+    if (c->ws.base) (void)hipFree(c->ws.base);
+    if (c->ws.done) (void)hipEventDestroy(c->ws.done);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     delete c;
 }
@@ -469,6 +499,13 @@ int mil_set_tile_count_buffer(mil_ctx *c, uint32_t *counts, uint32_t n_tiles)
     if (!c) return MIL_ERR_BAD_ARG;
     c->tile_counts = counts;
     c->tile_counts_cap = counts ? n_tiles : 0;
+    return MIL_OK;
+}
+
+int mil_set_two_kernel_threshold(mil_ctx *c, uint32_t min_point_lights)
+{
+    if (!c) return MIL_ERR_BAD_ARG;
+    c->two_kernel_min = min_point_lights;
     return MIL_OK;
 }
 
@@ -596,11 +633,43 @@ int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_dat
 
     const bool tiled = (n_point > 0 && !(flags & MIL_FLAG_NO_CULL)) || (p.has_shadow && p.shadow_lds && p.n_dir > 0);
     hipError_t le;
+    const uint32_t n_tiles = p.tiles_x * p.tiles_y;            // < 2^22: pitch * height < 2^30
     if (tiled) {
-        if (!pre) order_rows(c, slot, p, frame, bands, gb->y_offset, ex ? ex->point_lights : nullptr, n_point);
-        const uint32_t n_tiles = p.tiles_x * p.tiles_y;        // < 2^22: pitch * height < 2^30
         p.tile_counts = n_tiles <= c->tile_counts_cap ? c->tile_counts : nullptr;
         p.tile_stamps = n_tiles <= c->tile_stamps_cap ? c->tile_stamps : nullptr;
+    }
+    // The two-kernel form (k_bin -> k_shade) serves the fast-mode mil_light_ex launch with point lights; strict mode, the
+    // whole-frame launch, LDS-staged shadows and the wave-stamp diagnostics stay on k_tiled (MIL_TUNE bit 1024 forces it).
+    // (MIL_TUNE bit 2048: the stamp buffer, then 8 u32 per tile, goes to k_shade instead: one record per half tile)
+    if (tiled && (c->tune & 2048u)) p.tile_stamps = 2u * n_tiles <= c->tile_stamps_cap ? c->tile_stamps : nullptr;
+    // Below ~900 point lights k_tiled is the faster of the two on the 4K frame (256 lights: 101 us against 122; 1024: 234
+    // against 226; 4096: 625 against 487): the pre-pass costs what culling and sky tiles cost there.  The threshold is a
+    // context setting (mil_set_two_kernel_threshold; the parity tests set 1 so that small frames cover both kernels).
+    const bool many = n_point >= c->two_kernel_min;
+    bool two = tiled && many && !strict && !whole && !(flags & MIL_FLAG_NO_CULL) && !p.shadow_lds && (!p.tile_stamps || (c->tune & 2048u)) && !(c->tune & 1024u);
+    if (two) {
+        if (pre)          // the entry point that allocates nothing never grows the workspace
+            two = 2u * n_tiles <= c->ws.items_cap && ((n_tiles + MIL_WS_SHARDS - 1u) / MIL_WS_SHARDS) * 2u <= c->ws.seg_cap;
+        else if ((rc = workspace_reserve(c, p.tiles_x, p.tiles_y))) return rc;
+    }
+    if (two) {
+        TileWorkspace &w = c->ws;
+        if (!pre && w.used && w.last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, w.done, 0));      // one workspace per context
+        p.ws_shard_count = w.shard_count; p.ws_total = w.total; p.ws_shard_items = w.shard_items; p.ws_order = w.order;
+        p.ws_meta = w.meta; p.ws_lists = w.lists;
+        p.ws_items_cap = w.items_cap; p.ws_seg_cap = w.seg_cap;
+        const uint32_t want = (n_point + 63u) & ~63u;
+        p.ws_list_stride = want < w.list_stride_max ? want : w.list_stride_max;
+        HIP_TRY(c, hipMemsetAsync(w.shard_count, 0, (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4 + 256, s));
+        le = mil::fast::launch_bin((int)fmt, p, s);
+        if (le == hipSuccess) le = mil::fast::launch_order(p, s);
+        if (le == hipSuccess) le = mil::fast::launch_shade((int)fmt, p, s);
+        if (le == hipSuccess && !pre) {
+            HIP_TRY(c, hipEventRecord(w.done, s));
+            w.used = true; w.last_stream = s;
+        }
+    } else if (tiled) {
+        if (!pre) order_rows(c, slot, p, frame, bands, gb->y_offset, ex ? ex->point_lights : nullptr, n_point);
         le = strict ? mil::strict::launch_tiled((int)fmt, p, whole, s) : mil::fast::launch_tiled((int)fmt, p, whole, s);
     } else {
         le = strict ? mil::strict::launch_stream((int)fmt, p, whole, s) : mil::fast::launch_stream((int)fmt, p, whole, s);

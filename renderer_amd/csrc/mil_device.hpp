@@ -1028,9 +1028,11 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     const uint32_t ri = blk / bpr, tyi = (k_tune & 1u) || k_tiles_y > MIL_MAX_ROW_ORDER ? ri : (uint32_t)p.row_order[ri];
     const uint32_t txi = (blk - ri * bpr) * wpb + wv;
     if (txi >= k_tiles_x) return;                       // whole wave; nothing below synchronises across waves
-    // frame row / output row of this tile's local rows (band dealing: a tile never straddles two bands)
+    // frame row / output row of this tile's local rows (band dealing: a tile never straddles two bands).  Used by the unlit
+    // tile's early store path only; the later phases re-derive it from the kernarg block (two SGPRs held across the whole
+    // kernel were two more spilled into VGPR lanes)
     const uint32_t k_band = (tyi * TILE) >> k_band_shift;
-    const RowMap rm = { k_y_offset + k_band * k_band_extra, k_band * k_out_band_extra };
+    const RowMap rm_e = { k_y_offset + k_band * k_band_extra, k_band * k_out_band_extra };
     const uint64_t t_start = k_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
 
     // ---- 1. HBM -> LDS, coordinates clamped (not branched) so the loads are straight-line ----
@@ -1084,14 +1086,14 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll
                     for (int j = 0; j < 4; j++)
                         if (xin && (y0 + 4 * j) <= ylast)
-                            h[j] = frame_value(p, x, y0 + 4 * j, rm, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
+                            h[j] = frame_value(p, x, y0 + 4 * j, rm_e, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j + rm.o, h[j]);
+                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j + rm_e.o, h[j]);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j + rm.o);
+                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j + rm_e.o);
                 }
                 if (e_counts && lane == 0) e_counts[tyi * k_tiles_x + txi] = 0;
                 if (k_stamps && lane == 0) {
@@ -1127,6 +1129,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         lit4[j] = xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
     // a tile without a lit pixel (sky) has an empty box: no positions, no reductions, no culling
     if ((p.n_point > 0 || stage) && __builtin_amdgcn_ballot_w64(lit4[0] || lit4[1] || lit4[2] || lit4[3]) != 0) {
+        const RowMap rm = row_map(p, tyi * TILE);
 #if !MIL_STRICT
         f3 P4[4];    // the same packed evaluation as the shading passes (rows j, j + 1 together): identical positions
 #pragma unroll
@@ -1247,6 +1250,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll 1
         for (uint32_t j = 0; j < 4; j++) {
             const ShadeParams &p = kernarg_params();
+            const RowMap rm = row_map(p, tyi * TILE);
             const uint32_t y = y0 + 4 * j;
             const uint32_t u1 = s_tex[(0 + j) * 64 + lane], w2 = s_tex[(4 + j) * 64 + lane], u3 = s_tex[(8 + j) * 64 + lane];
             const float depth = __uint_as_float(s_tex[(12 + j) * 64 + lane]);
@@ -1293,6 +1297,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll 1
         for (uint32_t jp = 0; jp < 2; jp++) {
             const ShadeParams &p = kernarg_params();
+            const RowMap rm = row_map(p, tyi * TILE);
             const uint32_t ja = 2 * jp, ya = y0 + 4 * ja, yb = ya + 4;
             const v2u u1 = { s_tex[(0 + ja) * 64 + lane], s_tex[(1 + ja) * 64 + lane] };
             const v2u w2 = { s_tex[(4 + ja) * 64 + lane], s_tex[(5 + ja) * 64 + lane] };
@@ -1373,6 +1378,342 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 16);             // HW_REG_XCC_ID[3:0]
     }
 }
+
+#if !MIL_STRICT
+// ---------------------------------------------------------------------------------
+// K2, two-kernel form (fast mode, mil_light_ex): k_bin -> k_shade.
+//
+// k_tiled gives every 16x16 tile one wave that classifies, culls AND shades.  Measured on it (tools/stamps.py): half of the
+// waves of Scene A are sky tiles that live 5 us to store zeros while holding a 128-VGPR slot; every wave of a 4096-light
+// frame tests all 4096 lights against its own box (11 % of the instructions); a light is evaluated for the 128 pixels of a
+// pass when it reaches one (72 % lane efficiency); and the waves of the heaviest tiles (up to 380 us of a 600 us launch)
+// start whenever the row order gets to them, so the launch ends on a tail at a quarter of the wave slots.
+//
+//   k_bin    one workgroup per 64x64 MACRO tile, one wave per 16x16 tile, light on registers.  Reads the occlusion bytes
+//            (and the depth of lit tiles only); writes the exact zeros of unlit half tiles; boxes of the lit pixels of
+//            each 16x8 HALF tile (the same packed position evaluation the shading uses); culling in two levels - the
+//            16 waves test the lights against the macro tile's box together (1024 lights per step, survivors compacted
+//            into LDS in ascending order by ballot + mbcnt + a prefix over the waves' counts), then each wave tests the
+//            survivors against its two half-tile boxes and appends to their lists in the context's workspace, ascending;
+//            every lit half tile is appended to a COST BUCKET (by list length).
+//   k_shade  one wave per listed half tile, two pixels per lane (packed FP32), most expensive bucket first: texels
+//            straight into registers, directional lights + PCF, then the list, 64 records per block broadcast with
+//            v_readlane as in k_tiled.  No classification, no culling, no LDS.
+// The sums run in ascending light order as in k_tiled and in the brute-force loop: all three agree bit for bit.
+// ---------------------------------------------------------------------------------
+constexpr int BIN_TX = 4, BIN_TY = 4, BIN_WAVES = BIN_TX * BIN_TY;
+#ifndef MIL_SHADE_WAVES
+#define MIL_SHADE_WAVES 4      // waves per SIMD k_shade's registers are allocated for
+#endif
+constexpr uint32_t COARSE_MIN = 512, COARSE_CAP = 8192;
+
+DEV uint32_t cost_bucket(uint32_t len, bool brute)      // bucket 0 = most expensive; monotone in the list length
+{
+    if (brute) return 0u;
+    const uint32_t c = len < 32u ? (len >> 1) : 16u + min(15u, (len - 32u) >> 5);      // 16 steps of 2, then steps of 32 up to 512+
+    return (MIL_WS_BUCKETS - 1u) - c;
+}
+DEV void store_zero_rt(int fmt, void *out, uint32_t out_pitch, uint32_t x, uint32_t y)
+{
+    const size_t o = (size_t)y * out_pitch + x;
+    if (fmt == FMT_HDR) __builtin_nontemporal_store(v4f{ 0.0f, 0.0f, 0.0f, 1.0f }, (v4f *)out + o);
+    else __builtin_nontemporal_store(fmt == FMT_LDR ? 0u : 0xFF000000u, (uint32_t *)out + o);
+}
+DEV uint32_t wave_incl_prefix(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, o, 64);
+        if (lane >= (uint32_t)o) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt)
+{
+    __shared__ uint16_t s_coarse[COARSE_CAP];
+    __shared__ float s_box[BIN_WAVES][6];
+    __shared__ uint32_t s_cnt[64];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t macros_x = (p.tiles_x + BIN_TX - 1) / BIN_TX;
+    const uint32_t mby = blockIdx.x / macros_x, mbx = blockIdx.x - mby * macros_x;
+    const uint32_t txi = mbx * BIN_TX + (wv & 3u), tyi = mby * BIN_TY + (wv >> 2);
+    const bool tile_in = txi < p.tiles_x && tyi < p.tiles_y;       // no early return: the workgroup meets at barriers below
+    const uint32_t x = txi * TILE + (lane & 15u), y0 = tyi * TILE + (lane >> 4);
+    const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
+    const bool xin = tile_in && x < p.width;
+    const RowMap rm = row_map(p, tyi * TILE);
+
+    // ---- classify: occlusion bytes of the tile's 256 texels
+    uint32_t off[4];
+    bool lit4[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) { off[j] = min(y0 + 4 * j, ylast) * p.pitch + xc; __builtin_assume(off[j] < (1u << 30)); }
+    // Everything the wave will read is requested up front - occlusion bytes, depths (wasted on a sky tile: 4 of the 8 bytes
+    // a texel costs here) and the first 256 cull records - so that the wave pays ONE memory latency before its arithmetic
+    // instead of three in a row; the kernel is bound by that latency, not by bandwidth or issue.
+    const uint32_t n_point = p.n_point;
+    const v4f *cull = (const v4f *)p.point_cull;
+    const bool coarse = n_point > COARSE_MIN && n_point <= COARSE_CAP;      // uniform over the launch
+    uint32_t u2[4] = { 0u, 0u, 0u, 0u };
+    float dz[4] = { 1.0f, 1.0f, 1.0f, 1.0f };
+    v4f pc[4];
+    if (tile_in) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) u2[j] = p.albedo[off[j]];
+#pragma unroll
+        for (int j = 0; j < 4; j++) dz[j] = p.depth[off[j]];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)         // the records the first culling step tests (coarse: this wave's share of the first 4096)
+        pc[u] = cull[min(coarse ? (uint32_t)u * (BIN_WAVES * 64u) + wv * 64u + lane : 64u * u + lane, n_point - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) lit4[j] = xin && (y0 + 4 * j) <= ylast && (u2[j] >> 24) != 0;
+    const bool anyA = __builtin_amdgcn_ballot_w64(lit4[0] || lit4[1]) != 0, anyB = __builtin_amdgcn_ballot_w64(lit4[2] || lit4[3]) != 0;
+    // occlusion 0 multiplies every term (fs_deferred_lighting.glsl:63 and the extensions): an unlit half tile is exactly 0
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        if (xin && (y0 + 4 * j) <= ylast && !(j < 2 ? anyA : anyB)) store_zero_rt(fmt, p.out, p.out_pitch, x, y0 + 4 * j + rm.o);
+
+    // ---- boxes of the lit pixels of the two half tiles
+    const float INF = __builtin_inff();
+    f3 loA = { INF, INF, INF }, hiA = { -INF, -INF, -INF }, loB = loA, hiB = hiA;
+    if (anyA || anyB) {
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+            const PosT<v2f> q2 = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(y0 + 4 * jj + rm.g), (float)(y0 + 4 * jj + 4 + rm.g) },
+                                                       v2f{ dz[jj], dz[jj + 1] });
+            f3 &lo = jj ? loB : loA, &hi = jj ? hiB : hiA;
+            if (lit4[jj]) {
+                lo.x = fminf(lo.x, q2.P.x.x); lo.y = fminf(lo.y, q2.P.y.x); lo.z = fminf(lo.z, q2.P.z.x);
+                hi.x = fmaxf(hi.x, q2.P.x.x); hi.y = fmaxf(hi.y, q2.P.y.x); hi.z = fmaxf(hi.z, q2.P.z.x);
+            }
+            if (lit4[jj + 1]) {
+                lo.x = fminf(lo.x, q2.P.x.y); lo.y = fminf(lo.y, q2.P.y.y); lo.z = fminf(lo.z, q2.P.z.y);
+                hi.x = fmaxf(hi.x, q2.P.x.y); hi.y = fmaxf(hi.y, q2.P.y.y); hi.z = fmaxf(hi.z, q2.P.z.y);
+            }
+        }
+        if (anyA) wave_aabb(loA, hiA);
+        if (anyB) wave_aabb(loB, hiB);
+    }
+
+    // ---- level 1: the macro tile's box against all lights, by the 16 waves together
+    uint32_t coarse_n = 0;
+    if (coarse) {
+        if (lane == 0) {
+            s_box[wv][0] = fminf(loA.x, loB.x); s_box[wv][1] = fminf(loA.y, loB.y); s_box[wv][2] = fminf(loA.z, loB.z);
+            s_box[wv][3] = fmaxf(hiA.x, hiB.x); s_box[wv][4] = fmaxf(hiA.y, hiB.y); s_box[wv][5] = fmaxf(hiA.z, hiB.z);
+        }
+        __syncthreads();
+        f3 lo = { INF, INF, INF }, hi = { -INF, -INF, -INF };
+        if (lane < (uint32_t)BIN_WAVES) {
+            lo = f3{ s_box[lane][0], s_box[lane][1], s_box[lane][2] };
+            hi = f3{ s_box[lane][3], s_box[lane][4], s_box[lane][5] };
+        }
+        wave_aabb(lo, hi);
+        if (lo.x <= hi.x) {                                               // the same for every wave of the workgroup
+#pragma unroll 1
+            for (uint32_t base = 0; base < n_point; base += 4u * BIN_WAVES * 64u) {
+                unsigned long long m4[4];
+                uint32_t li4[4];
+                v4f c4[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    li4[t] = base + (uint32_t)t * (BIN_WAVES * 64u) + wv * 64u + lane;
+                    c4[t] = base == 0 ? pc[t] : cull[min(li4[t], n_point - 1)];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const bool pass = li4[t] < n_point && box_d2(c4[t], lo, hi) < c4[t].w * c4[t].w;
+                    m4[t] = __builtin_amdgcn_ballot_w64(pass);
+                    if (lane == 0) s_cnt[t * BIN_WAVES + wv] = (uint32_t)__builtin_popcountll(m4[t]);
+                }
+                __syncthreads();
+                const uint32_t cnt = s_cnt[lane];
+                const uint32_t incl = wave_incl_prefix(cnt, lane), excl = incl - cnt;     // (step, wave) order = ascending light index
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t o = coarse_n + (uint32_t)__builtin_amdgcn_readlane((int)excl, t * BIN_WAVES + (int)wv) +
+                                       __builtin_amdgcn_mbcnt_hi((uint32_t)(m4[t] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m4[t], 0u));
+                    if ((m4[t] >> lane) & 1ull) s_coarse[o] = (uint16_t)li4[t];
+                }
+                coarse_n += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- level 2: this wave's two half-tile boxes against the survivors (or against all lights), lists in ascending order
+    const uint32_t src_n = coarse ? coarse_n : n_point, stride = p.ws_list_stride;
+    const uint32_t itemA = 2u * (tyi * p.tiles_x + txi);
+    uint32_t lenA = 0, lenB = 0, cntU = 0;
+    if (anyA || anyB) {
+        uint16_t *const listA = p.ws_lists + (size_t)itemA * stride, *const listB = listA + stride;
+#pragma unroll 1
+        for (uint32_t b0 = 0; b0 < src_n; b0 += 256u) {
+            uint32_t li4[4];
+            v4f c4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                 // four records per lane requested together: one latency per 256 candidates
+                const uint32_t k = min(b0 + 64u * u + lane, src_n - 1);
+                li4[u] = coarse ? (uint32_t)s_coarse[k] : k;
+                c4[u] = (!coarse && b0 == 0) ? pc[u] : cull[li4[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool valid = b0 + 64u * u + lane < src_n;
+                const float r2 = c4[u].w * c4[u].w;
+                const bool pA = valid && anyA && box_d2(c4[u], loA, hiA) < r2, pB = valid && anyB && box_d2(c4[u], loB, hiB) < r2;
+                const unsigned long long mA = __builtin_amdgcn_ballot_w64(pA), mB = __builtin_amdgcn_ballot_w64(pB);
+                const uint32_t posA = lenA + __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+                const uint32_t posB = lenB + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+                if (pA && posA < stride) listA[posA] = (uint16_t)li4[u];
+                if (pB && posB < stride) listB[posB] = (uint16_t)li4[u];
+                lenA += (uint32_t)__builtin_popcountll(mA); lenB += (uint32_t)__builtin_popcountll(mB);
+                cntU += (uint32_t)__builtin_popcountll(mA | mB);
+            }
+        }
+    }
+    // ---- append the lit half tiles to their cost buckets (one returning add per item on the tile's shard of the counters)
+    if (lane == 0 && tile_in && (anyA || anyB)) {
+        const uint32_t tile = tyi * p.tiles_x + txi, shard = tile % MIL_WS_SHARDS;
+        uint32_t *const seg = p.ws_shard_items + (size_t)shard * MIL_WS_BUCKETS * p.ws_seg_cap;
+        if (anyA) {
+            const bool brute = lenA > stride;             // more lights reach the half tile than a list holds: brute force there
+            const uint32_t b = cost_bucket(lenA, brute);
+            p.ws_meta[itemA] = brute ? MIL_WS_BRUTE : lenA;
+            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = itemA;
+        }
+        if (anyB) {
+            const bool brute = lenB > stride;
+            const uint32_t b = cost_bucket(lenB, brute);
+            p.ws_meta[itemA + 1] = brute ? MIL_WS_BRUTE : lenB;
+            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = itemA + 1;
+        }
+    }
+    if (lane == 0 && tile_in && p.tile_counts) p.tile_counts[tyi * p.tiles_x + txi] = cntU;
+}
+
+// k_order: one wave per (bucket, shard) segment.  The segments laid out bucket by bucket = one launch order, most expensive
+// half tiles first; ws_total = their number.  Every wave reads the whole 64 x 32 counter table (its lane = one shard's row,
+// eight 16-byte loads in flight together) and derives its own offset: no second pass, no dependence between the waves.
+__global__ __launch_bounds__(64) void k_order(const ShadeParams p)
+{
+    const uint32_t lane = threadIdx.x, b = blockIdx.x / MIL_WS_SHARDS, shard = blockIdx.x % MIL_WS_SHARDS;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4 *row = (const u4 *)(p.ws_shard_count + lane * MIL_WS_BUCKETS);      // lane = shard (MIL_WS_SHARDS = 64)
+    u4 c[MIL_WS_BUCKETS / 4];
+#pragma unroll
+    for (int i = 0; i < (int)MIL_WS_BUCKETS / 4; i++) c[i] = row[i];
+    uint32_t before = 0, own = 0, all = 0;              // this shard's counts in buckets < b, in bucket b, in all buckets
+#pragma unroll
+    for (int i = 0; i < (int)MIL_WS_BUCKETS; i++) {
+        const uint32_t v = c[i / 4][i % 4];
+        before += (uint32_t)i < b ? v : 0u;
+        own = (uint32_t)i == b ? v : own;
+        all += v;
+    }
+    const uint32_t incl_own = wave_incl_prefix(own, lane);
+    uint32_t tb = before, ta = all;                      // wave sums
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { tb += (uint32_t)__shfl_xor((int)tb, o, 64); ta += (uint32_t)__shfl_xor((int)ta, o, 64); }
+    const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)own, (int)shard);
+    const uint32_t dst = tb + (uint32_t)__builtin_amdgcn_readlane((int)(incl_own - own), (int)shard);
+    const uint32_t *src = p.ws_shard_items + ((size_t)shard * MIL_WS_BUCKETS + b) * p.ws_seg_cap;
+    for (uint32_t k = lane; k < mine; k += 64) p.ws_order[dst + k] = src[k];
+    if (blockIdx.x == 0 && lane == 0) *p.ws_total = ta;
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParams p)
+{
+    // four independent waves per workgroup, one item each (no barrier, no LDS): single-wave workgroups are admitted to a CU
+    // in smaller numbers than its wave slots
+    const uint32_t lane = threadIdx.x & 63u, w = blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (w >= *(const uint32_t *)p.ws_total) return;       // beyond the last listed half tile (the grid is the upper bound)
+    const uint64_t t_start = p.tile_stamps ? __builtin_amdgcn_s_memrealtime() : 0;      // diagnostics only (100 MHz)
+    const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ws_order[w]);
+    const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ws_meta[item]);
+    const uint32_t tile = item >> 1, tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
+    const uint32_t x = txi * TILE + (lane & 15u), ya = tyi * TILE + (item & 1u) * 8u + (lane >> 4), yb = ya + 4;
+    const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
+    const uint32_t ia = min(ya, ylast) * p.pitch + xc, ib = min(yb, ylast) * p.pitch + xc;
+    __builtin_assume(ia < (1u << 30)); __builtin_assume(ib < (1u << 30));
+    const v2u w2 = { __builtin_nontemporal_load(p.albedo + ia), __builtin_nontemporal_load(p.albedo + ib) };
+    const v2u u1 = { __builtin_nontemporal_load(p.normal + ia), __builtin_nontemporal_load(p.normal + ib) };
+    const v2u u3 = { __builtin_nontemporal_load(p.rm + ia), __builtin_nontemporal_load(p.rm + ib) };
+    const v2f depth = { __builtin_nontemporal_load(p.depth + ia), __builtin_nontemporal_load(p.depth + ib) };
+    // the list's first block of records, requested with the texels
+    const bool brute = (meta & MIL_WS_BRUTE) != 0;
+    const uint32_t len = brute ? 0u : meta;
+    const uint16_t *const list = p.ws_lists + (size_t)item * p.ws_list_stride;
+    auto gather = [&](uint32_t kb, v4f &ga, v4f &gb) {
+        const uint32_t li = list[min(kb + lane, len - 1)];
+        ga = point_rec_a_v(p, li); gb = point_rec_b_v(p, li);
+    };
+    v4f ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
+    if (len) gather(0, ra, rb);
+    const RowMap rm = row_map(p, tyi * TILE);
+    const bool inA = x < p.width && ya <= ylast, inB = x < p.width && yb <= ylast;
+    const bool litA = inA && (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
+
+    Px2 q;
+    setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth), u1, w2, u3);
+    V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+    const bool do_shadow = p.has_shadow && p.n_dir > 0;
+    v2f shadow = { 1.0f, 1.0f };
+    if (do_shadow) {
+        ShadowTap ta, tb;
+        shadow_tap2(q.P, p, ta, tb);
+        if (litA) shadow.x = pcf_direct(ta, p);
+        if (litB) shadow.y = pcf_direct(tb, p);
+    }
+    for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
+    if (len) {
+        uint32_t kb = 0;
+#pragma unroll 1
+        for (;;) {
+            const uint32_t n = min(64u, len - kb);
+#pragma unroll 1
+            for (uint32_t k = 0; k < n; k++) {
+                const v4f a = bcast4(ra, (int)k);
+                V3<v2f> Lv;
+                const v2f d2 = point_d2_2(q, a, Lv);
+                const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
+                if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;       // wave-uniform: nobody in range
+                point_eval2(q, bcast4(rb, (int)k), Lv, d2, on0, on1, r);
+            }
+            kb += 64;
+            if (kb >= len) break;
+            gather(kb, ra, rb);
+        }
+    } else if (brute) {                                   // every light, as the brute-force kernel (same order, same bits)
+#pragma unroll 1
+        for (uint32_t l = 0; l < p.n_point; l++) {
+            const v4f a = point_rec_a(p, l);
+            V3<v2f> Lv;
+            const v2f d2 = point_d2_2(q, a, Lv);
+            const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
+            if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;
+            point_eval2(q, point_rec_b(p, l), Lv, d2, on0, on1, r);
+        }
+    }
+    if (p.has_ambient) {
+        const v2f ka = q.occ * (1.0f / 255.0f);           // albedo * occlusion re-decoded from the texel
+        r.x = fma_((v2f)(p.ambient[0]), tof(w2 & 0xFFu) * ka, r.x);
+        r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
+        r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
+    }
+    if (inA) emit_pixel<FMT, false>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
+    if (inB) emit_pixel<FMT, false>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
+    if (p.tile_stamps && lane == 0) {                     // diagnostics (MIL_TUNE bit 2048): per ITEM start, end, list length, launch index
+        uint32_t *st = p.tile_stamps + 4 * (size_t)item;
+        st[0] = (uint32_t)t_start; st[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); st[2] = brute ? 0xFFFFu : len; st[3] = w;
+
+    }
+}
+#endif
 
 // ---------------------------------------------------------------------------------
 // K4: tonemap + pack (fs_tonemap.glsl:23-27).  Block = 64 x 4 pixels.
@@ -1838,6 +2179,26 @@ hipError_t launch_accumulate(const AccumParams &p, hipStream_t s)
     return launch_k(k_accumulate, dim3((p.count + 255) / 256), dim3(256), 0, s, p);
 }
 #if !MIL_STRICT
+hipError_t launch_bin(int fmt, const ShadeParams &p, hipStream_t s)
+{
+    const uint32_t macros = ((p.tiles_x + BIN_TX - 1) / BIN_TX) * ((p.tiles_y + BIN_TY - 1) / BIN_TY);
+    void *args[] = { (void *)&p, (void *)&fmt };
+    return hipLaunchKernel((const void *)k_bin, dim3(macros), dim3(64 * BIN_WAVES), args, 0, s);
+}
+hipError_t launch_order(const ShadeParams &p, hipStream_t s)
+{
+    return launch_k(k_order, dim3(MIL_WS_SHARDS * MIL_WS_BUCKETS), dim3(64), 0, s, p);
+}
+hipError_t launch_shade(int fmt, const ShadeParams &p, hipStream_t s)
+{
+    const dim3 grid((2u * p.tiles_x * p.tiles_y + 3u) / 4u), block(256);        // upper bound: every half tile lit
+    switch (fmt) {
+    case FMT_HDR: return launch_k(k_shade<FMT_HDR>, grid, block, 0, s, p);
+    case FMT_LDR: return launch_k(k_shade<FMT_LDR>, grid, block, 0, s, p);
+    case FMT_SRGB8: return launch_k(k_shade<FMT_SRGB8>, grid, block, 0, s, p);
+    default: return launch_k(k_shade<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p);
+    }
+}
 hipError_t launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)
 {
     dim3 block(64, 4), grid((p.width + 63) / 64, (p.height + 3) / 4);

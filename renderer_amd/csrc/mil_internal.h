@@ -29,6 +29,20 @@ struct Slot {
     uint64_t gen = 0;            // bumped whenever new content is staged into this slot
 };
 
+// Workspace of the two-kernel tiled path (k_bin -> k_shade, mil_device.hpp): per half tile a light list, its length and a
+// place in one of the cost buckets.  Sized for the largest frame the context has shaded so far: like the reference, which
+// recreates its attachments when the window is resized (render/pbr/mod.rs:263-346), a LARGER frame reallocates it (the only
+// allocation a per-frame call can make; it synchronises the device); the steady state allocates nothing.
+struct TileWorkspace {
+    uint8_t *base = nullptr;            // one allocation
+    uint32_t *shard_count = nullptr, *total = nullptr, *shard_items = nullptr, *order = nullptr, *meta = nullptr;
+    uint16_t *lists = nullptr;
+    uint32_t items_cap = 0, list_stride_max = 0, seg_cap = 0;
+    hipEvent_t done = nullptr;          // the last launch that used it ...
+    hipStream_t last_stream = nullptr;  // ... and its stream: a launch on another stream waits for it (one workspace per context)
+    bool used = false;
+};
+
 constexpr int ROW_ORDER_CACHE = 16;
 struct RowOrderEntry {
     uint16_t order[MIL_MAX_ROW_ORDER];
@@ -63,6 +77,8 @@ struct mil_ctx {
     uint32_t tonemap_rows = 0;   // K4 rows per lane            } tuning knobs: read from the environment only when
     uint32_t fxaa_rows = 2;      // K5 output rows per lane      } MIL_DEBUG=1 is set (mil_create); the defaults are what
     uint32_t k1_rows = 1;        // K1 pixels per lane           } the parity suite covers
+    milhost::TileWorkspace ws;
+    uint32_t two_kernel_min = MIL_TWO_KERNEL_DEFAULT;   // point lights from which the k_bin -> k_shade form is used (fast mode)
     uint8_t *static_scratch = nullptr;   // this device's copy of mil_noalloc.hip's __device__ array (hipGetSymbolAddress)
     int last_hip = 0;
 };

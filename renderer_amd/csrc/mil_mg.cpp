@@ -68,7 +68,7 @@ struct Piece { uint32_t local0, rows, frame0; };
 struct Local {                      // one rank this process drives
     int rank = 0, device = 0;
     mil_ctx *ctx = nullptr;
-    hipStream_t compute = nullptr, compute_first = nullptr, gather = nullptr;   // compute_first: higher priority, chunk 0 of a frame
+    hipStream_t compute = nullptr, gather = nullptr;
     ncclComm_t comm = nullptr;
     std::vector<hipEvent_t> chunk_done;      // compute -> gather, one per chunk
     hipEvent_t gathered = nullptr;           // gather stream: the rank's previous frame has left its output buffer
@@ -155,14 +155,11 @@ int create_common(mil_mg *m, const mil_mg_config *cfg)
         int rc = mil_create(&l.ctx, l.device, cfg->max_point_lights);
         if (rc) return rc;
         MG_HIP(m, hipSetDevice(l.device));
-        // The first chunk of a frame runs on a higher-priority stream beside the rest of the frame on the other: the GPU hands
-        // its workgroups out first, so the chunk finishes (and its gather starts) early, and the rest fills the slots its tail
-        // leaves idle - two launches one after the other on ONE stream pay the tail of heavy tiles twice (8K / 4096 lights,
-        // one eighth of the frame: 405 us as one launch, 553 as two on one stream, 461 as two on prioritised streams).
-        int least = 0, greatest = 0;
-        MG_HIP(m, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        MG_HIP(m, hipStreamCreateWithPriority(&l.compute, hipStreamNonBlocking, least));
-        MG_HIP(m, hipStreamCreateWithPriority(&l.compute_first, hipStreamNonBlocking, greatest));
+        // One compute stream per rank.  (Measured, 8K / 4096 lights, one eighth of the frame: 405 us as one launch, 553 as two
+        // launches on one stream - the tail of the heavy tiles is paid per launch - and 461 with the first chunk on a
+        // higher-priority stream beside the second; but with 8 ranks x 3 streams on the 4 hardware queues of this pool
+        // (GPU_MAX_HW_QUEUES) mixed-priority streams stopped making progress, so every chunk runs on the one stream.)
+        MG_HIP(m, hipStreamCreateWithFlags(&l.compute, hipStreamNonBlocking));
         MG_HIP(m, hipStreamCreateWithFlags(&l.gather, hipStreamNonBlocking));
         MG_HIP(m, hipEventCreateWithFlags(&l.gathered, hipEventDisableTiming));
         const uint32_t n = cfg->chunks ? cfg->chunks : 4u;
@@ -225,7 +222,6 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
         if (l.gathered_valid) {
             MG_HIP(m, hipSetDevice(l.device));
             MG_HIP(m, hipStreamWaitEvent(l.compute, l.gathered, 0));
-            MG_HIP(m, hipStreamWaitEvent(l.compute_first, l.gathered, 0));
         }
     const size_t row_bytes = (size_t)push->resolution[0] * bpp;
     for (size_t c = 0; c < n_chunks; c++) {
@@ -243,7 +239,7 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
             const mil_frame_matrix_data *f = per_rank_frame ? &frames[i] : frames;
             const uint32_t out_pitch = in_place[i] ? dst_pitch_px : r.out_pitch_px;
             int rc;
-            hipStream_t cs = (c == 0 && n_chunks > 1) ? l.compute_first : l.compute;
+            hipStream_t cs = l.compute;
             if (strips && m->cfg.band_rows) {
                 const mil_band_layout b = { m->cfg.band_rows, (uint32_t)m->world, (uint32_t)l.rank, k0 / m->cfg.band_rows };
                 gb.y_offset = 0;
@@ -323,7 +319,6 @@ void mil_mg_destroy(mil_mg *m)
     for (Local &l : m->locals) {
         (void)hipSetDevice(l.device);
         if (l.compute) (void)hipStreamSynchronize(l.compute);
-        if (l.compute_first) (void)hipStreamSynchronize(l.compute_first);
         if (l.gather) (void)hipStreamSynchronize(l.gather);
     }
     for (Local &l : m->locals) {
@@ -332,7 +327,6 @@ void mil_mg_destroy(mil_mg *m)
         for (hipEvent_t e : l.chunk_done) if (e) (void)hipEventDestroy(e);
         if (l.gathered) (void)hipEventDestroy(l.gathered);
         if (l.compute) (void)hipStreamDestroy(l.compute);
-        if (l.compute_first) (void)hipStreamDestroy(l.compute_first);
         if (l.gather) (void)hipStreamDestroy(l.gather);
         if (l.ctx) mil_destroy(l.ctx);
     }
@@ -454,7 +448,6 @@ int mil_mg_sync(mil_mg *m)
     for (Local &l : m->locals) {
         MG_HIP(m, hipSetDevice(l.device));
         MG_HIP(m, hipStreamSynchronize(l.compute));
-        MG_HIP(m, hipStreamSynchronize(l.compute_first));
         MG_HIP(m, hipStreamSynchronize(l.gather));
         if (l.comm && rccl().ok) {
             ncclResult_t ae = ncclSuccess;

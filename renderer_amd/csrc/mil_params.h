@@ -10,6 +10,10 @@ namespace mil {
 
 #define MIL_DIR_INLINE 4u
 #define MIL_MAX_ROW_ORDER 288u   // tile rows of a 4608-row frame; taller frames use plain order
+#define MIL_WS_BUCKETS 32u       // cost buckets of the two-kernel tiled path
+#define MIL_WS_SHARDS 64u        // counter shards per bucket
+#define MIL_WS_LIST_MAX 1024u    // entries a half-tile list holds at most; a half tile more lights reach is shaded by brute force
+#define MIL_WS_BRUTE 0x80000000u
 
 struct ShadeParams {
     // G-buffer planes (device), see mil_gbuffer
@@ -51,6 +55,18 @@ struct ShadeParams {
     uint32_t *tile_counts;      // optional per-tile list length (diagnostics)
     uint32_t *tile_stamps;      // optional 4 x u32 per tile: start, end (100 MHz ticks), list length, HW_ID (diagnostics)
     const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
+    // Two-kernel tiled path (k_bin -> k_shade; fast mode): the context's workspace (mil_internal.h TileWorkspace).  An ITEM is a
+    // 16x8 half of a 16x16 screen tile: item = 2 * (tile_y * tiles_x + tile_x) + half.
+    // k_bin appends every lit half tile to a cost bucket (0 = most expensive).  One counter word takes ~88 returning atomics
+    // per microsecond, so the counters are SHARDED (workgroup g uses shard g % MIL_WS_SHARDS, one add per workgroup and
+    // bucket); k_order then lays the segments out bucket by bucket in ws_order, which k_shade walks in launch order.
+    uint32_t *ws_shard_count;       // [MIL_WS_SHARDS][MIL_WS_BUCKETS], then ws_total: zeroed before k_bin
+    uint32_t *ws_shard_items;       // [MIL_WS_SHARDS][MIL_WS_BUCKETS][ws_seg_cap] item ids
+    uint32_t *ws_order;             // [ws_items_cap] item ids, most expensive first
+    uint32_t *ws_total;             // number of listed items
+    uint32_t *ws_meta;              // [ws_items_cap] list length | MIL_WS_BRUTE
+    uint16_t *ws_lists;             // [ws_items_cap][ws_list_stride] light indices, ascending
+    uint32_t ws_items_cap, ws_list_stride, ws_seg_cap;
     // whole-frame launch (mil_shade_frame): the sky and transparency-resolve subpasses folded into the store
     uint32_t has_sky;
     uint32_t accum_pitch, reveal_pitch;
@@ -109,6 +125,9 @@ hipError_t launch_stream(int fmt, const ShadeParams &p, bool frame, hipStream_t 
 hipError_t launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s);
 hipError_t launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 hipError_t launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
+hipError_t launch_bin(int fmt, const ShadeParams &p, hipStream_t s);                 // k_bin: classify, cull, bucket (then:)
+hipError_t launch_order(const ShadeParams &p, hipStream_t s);                        // k_order: buckets -> one launch order
+hipError_t launch_shade(int fmt, const ShadeParams &p, hipStream_t s);               // k_shade: one wave per listed half tile
 hipError_t launch_fxaa(const FxaaParams &p, hipStream_t s);
 hipError_t launch_sky(const SkyParams &p, hipStream_t s);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);

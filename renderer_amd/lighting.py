@@ -16,7 +16,7 @@ import numpy as np
 from . import ubo
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmil.so')
+LIB_PATH = os.environ.get('MIL_LIB', os.path.join(_HERE, 'libmil.so'))
 
 OUT_HDR, OUT_LDR, OUT_SRGB8, OUT_SRGB8_VIA_LDR = 0, 1, 2, 3
 FLAG_STRICT, FLAG_NO_CULL, FLAG_SHADOW_LDS = 1, 2, 4
@@ -28,7 +28,7 @@ EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'm
            'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame',
            'mil_transparency_accumulate', 'mil_import_external_memory', 'mil_alloc_exportable_memory',
            'mil_release_external_memory', 'mil_shade_bands', 'mil_band_local_rows', 'mil_row_weights',
-           'mil_light_ex_noalloc']
+           'mil_light_ex_noalloc', 'mil_set_two_kernel_threshold']
 
 
 class MilError(RuntimeError):
@@ -108,6 +108,7 @@ def load_library(path=LIB_PATH):
         lib.mil_release_external_memory.argtypes = [vp, vp]
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
         lib.mil_light_ex_noalloc.argtypes = lib.mil_light_ex.argtypes
+        lib.mil_set_two_kernel_threshold.argtypes = [vp, u32]
         lib.mil_shade_bands.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras),
                                         ctypes.POINTER(FramePasses), ctypes.POINTER(BandLayout), vp, u32, ctypes.c_int,
                                         ctypes.c_int, u32, vp]
@@ -164,6 +165,10 @@ class LightingPass:
         self._check(self.lib.mil_create(ctypes.byref(h), device, max_point_lights), None)
         self.ctx = h
         self._tile_counts = self._tile_stamps = None     # diagnostic buffers the ctx points at: kept alive here
+
+    def set_two_kernel_threshold(self, min_point_lights):
+        """mil_set_two_kernel_threshold: 1 = every culled fast-mode launch goes k_bin -> k_shade, 0xFFFFFFFF = none does."""
+        self._check(self.lib.mil_set_two_kernel_threshold(self.ctx, min_point_lights))
 
     def close(self):
         if getattr(self, 'ctx', None):

@@ -1,0 +1,154 @@
+"""The two-kernel form of the tiled lighting launch (k_bin -> k_order -> k_shade, csrc/mil_device.hpp), which fast-mode
+mil_light_ex takes from MIL_TWO_KERNEL_DEFAULT point lights on, forced here (threshold 1) onto frames the oracle finishes
+in seconds.  Bars as everywhere: index / integer work (lists, buckets, order, strips, bands) bit-exact - the result must
+equal the brute-force launch and the one-kernel form bit for bit - and the fast arithmetic within 1e-3 + 1e-4 |b| (+ the
+conditioning term) of the float64 oracle.  What the shaders are: fs_deferred_lighting.glsl:40-67, inc_brdf.glsl:2-63."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from renderer_amd import lighting, synth, ubo
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+AMB = (0.03, 0.03, 0.03)
+NEVER = 0xFFFFFFFF
+
+
+@pytest.fixture(scope='module')
+def two():
+    p = lighting.LightingPass(0, max_point_lights=4096)
+    p.set_two_kernel_threshold(1)
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope='module')
+def one():
+    p = lighting.LightingPass(0, max_point_lights=4096)
+    p.set_two_kernel_threshold(NEVER)
+    yield p
+    p.close()
+
+
+def scene(kind, w, h, n_point, shadow, seed=0x5EED0000):
+    cam = synth.sweep_camera(w, h)
+    gb = synth.scene_sweep(w, h, cam, device=DEV) if kind == 'sweep' else synth.scene_noise(w, h, seed, device=DEV)
+    dl = ubo.default_directional_lights()
+    pl = synth.point_light_field(n_point, seed + 1)
+    sh = synth.shadow_setup(dl[0, 0:3], shadow, device=DEV) if shadow else None
+    return gb, cam.frame_matrix_data(), dl, pl, sh
+
+
+def same(a, b):
+    return torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+@pytest.mark.parametrize('kind,w,h,n_point,shadow', [('sweep', 320, 180, 256, 128), ('sweep', 100, 60, 2500, 0), ('noise', 64, 48, 300, 64),
+                                                     ('sweep', 130, 77, 9, 32), ('noise', 17, 5, 40, 0), ('sweep', 1, 1, 3, 0),
+                                                     ('sweep', 640, 360, 600, 256), ('sweep', 200, 120, 5000, 0)])
+def test_two_kernel_equals_one_kernel_and_brute_force(two, one, kind, w, h, n_point, shadow):
+    """Every output format; 600 lights take the two-level culling (more than COARSE_MIN), 5000 the coarse list in LDS near
+    its capacity; 2500 lights on 100 x 60 put several hundred on every half tile."""
+    if n_point > 4096:
+        two2, one2 = lighting.LightingPass(0, n_point), lighting.LightingPass(0, n_point)
+        two2.set_two_kernel_threshold(1); one2.set_two_kernel_threshold(NEVER)
+    else:
+        two2, one2 = two, one
+    gb, frame, dl, pl, sh = scene(kind, w, h, n_point, shadow)
+    for fmt in (lighting.OUT_HDR, lighting.OUT_LDR, lighting.OUT_SRGB8, lighting.OUT_SRGB8_VIA_LDR):
+        a = two2.light_ex(gb, frame, dl, pl, AMB, sh, fmt=fmt)
+        assert same(a, one2.light_ex(gb, frame, dl, pl, AMB, sh, fmt=fmt)), fmt
+        assert same(a, one2.light_ex(gb, frame, dl, pl, AMB, sh, fmt=fmt, flags=lighting.FLAG_NO_CULL)), fmt
+    counts = two2.tile_counts(gb)
+    two2.light_ex(gb, frame, dl, pl, AMB, sh)
+    two2.tile_counts(gb, enable=False)
+    c1 = one2.tile_counts(gb)
+    one2.light_ex(gb, frame, dl, pl, AMB, sh)
+    one2.tile_counts(gb, enable=False)
+    # the union of a tile's two half-tile lists never holds more than the one-kernel form's tile list, and is not empty where that is not
+    assert torch.all(counts <= c1) and torch.equal(counts > 0, c1 > 0) or n_point > 1024      # (one-kernel lists are capped per round)
+    if n_point > 4096:
+        two2.close(); one2.close()
+
+
+def test_two_kernel_lists_beyond_capacity_fall_back_to_brute_force(two, one, coracle):
+    """More lights reach a half tile than a workspace list holds (1024): that half tile is shaded by the brute-force loop,
+    still in ascending light order: == the one-kernel form (which takes rounds) bit for bit; strict stays == the C oracle."""
+    gb, frame, dl, pl, sh = scene('sweep', 80, 48, 1500, 64)
+    pl = pl.copy()
+    pl[:, 3] = 60.0
+    pl[:, 7] = 0.01
+    a = two.light_ex(gb, frame, dl, pl, AMB, sh)
+    assert same(a, one.light_ex(gb, frame, dl, pl, AMB, sh))
+    assert same(a, one.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL))
+    g = synth.to_numpy(gb)
+    ref = coracle.shade(g['normal'], g['albedo_occ'], g['rough_metal'], g['depth'], frame, dl, point_lights=pl, ambient=AMB,
+                        shadow=dict(sh, map=sh['map'].cpu().numpy()))
+    strict = two.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_STRICT).cpu().numpy()
+    assert np.array_equal(strict.view(np.uint32), ref.view(np.uint32))
+
+
+def test_two_kernel_strips_bands_pitch_and_streams(two, one):
+    """Strips (y_offset), dealt bands, planes and output as views into wider images, alternating streams (one workspace per
+    context: launches on different streams are serialised), frames of changing size (the workspace grows), all == monolithic."""
+    w, h = 256, 144
+    gb, frame, dl, pl, sh = scene('sweep', w, h, 90, 128)
+    full = two.light_ex(gb, frame, dl, pl, AMB, sh)
+    for y0, y1 in ((0, 48), (37, 101), (96, 144)):
+        strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+        strip['y_offset'] = y0
+        assert same(two.light_ex(strip, frame, dl, pl, AMB, sh), full[y0:y1])
+    for band, n in ((16, 3), (32, 2)):
+        out = torch.zeros_like(full)
+        for r in range(n):
+            rows = torch.from_numpy(lighting.band_rows_of_rank(h, band, n, r)).to(DEV)
+            part = {k: (v[rows].contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()}
+            part['y_offset'] = 0
+            if r == 0:
+                two.shade_bands(part, frame, dl, (band, n, r), pl, AMB, sh, fmt=lighting.OUT_HDR, out=out, out_is_frame=True)
+            else:
+                out[rows] = two.shade_bands(part, frame, dl, (band, n, r), pl, AMB, sh, fmt=lighting.OUT_HDR)
+        assert same(out, full), (band, n)
+    big = {k: (torch.nn.functional.pad(v, (3, 9)) if torch.is_tensor(v) else v) for k, v in gb.items()}
+    view = {k: (v[:, 3:3 + w] if torch.is_tensor(v) else v) for k, v in big.items()}
+    outbuf = torch.full((h, w + 11, 4), -7.0, device=DEV)
+    got = two.light_ex(view, frame, dl, pl, AMB, sh, out=outbuf[:, 5:5 + w])
+    assert same(got, full) and torch.all(outbuf[:, :5] == -7.0) and torch.all(outbuf[:, 5 + w:] == -7.0)
+    streams = [torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)]
+    torch.cuda.synchronize()
+    outs = [two.light_ex(gb, frame, dl, pl, AMB, sh, stream=streams[i % 2]) for i in range(6)]
+    torch.cuda.synchronize()
+    assert all(same(o, full) for o in outs)
+    # a frame larger than the 4K reservation: the workspace is reallocated, then smaller frames again
+    gb2, frame2, dl2, pl2, _ = scene('sweep', 4096, 2304, 64, 0)
+    a = two.light_ex(gb2, frame2, dl2, pl2, AMB, None, fmt=lighting.OUT_LDR)
+    assert same(a, one.light_ex(gb2, frame2, dl2, pl2, AMB, None, fmt=lighting.OUT_LDR))
+    assert same(two.light_ex(gb, frame, dl, pl, AMB, sh), full)
+
+
+def test_two_kernel_fast_tolerance_and_noalloc(two, coracle):
+    gb, frame, dl, pl, sh = scene('sweep', 320, 180, 200, 0)
+    g = synth.to_numpy(gb)
+    planes = (g['normal'], g['albedo_occ'], g['rough_metal'], g['depth'])
+    r64, cond = coracle.shade_f64(*planes, frame, dl, point_lights=pl, ambient=AMB, want_cond=True)
+    fast = two.light_ex(gb, frame, dl, pl, AMB, None).cpu().numpy()
+    err = np.abs(fast[..., :3] - r64[..., :3])
+    assert np.all(err <= 1e-3 + 1e-4 * np.abs(r64[..., :3]) + 8 * 2.0 ** -24 * cond) and np.all(fast[..., 3] == 1.0)
+    # the entry point that allocates nothing takes the two kernels too (its workspace was reserved at mil_create)
+    a = two.light_ex_noalloc(gb, frame, dl, torch.from_numpy(pl).to(DEV), AMB, None)
+    assert same(a, two.light_ex(gb, frame, dl, pl, AMB, None))
+
+
+def test_two_kernel_randomised_sweep(two):
+    """Forty configurations of tools/fuzz_parity.py with every culled fast-mode launch going through k_bin -> k_shade."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import fuzz_parity
+    fuzz_parity.coracle.build()
+    fails = []
+    for seed in range(3000, 3040):
+        fails += fuzz_parity.one(two, seed)
+    assert not fails, fails
