@@ -50,6 +50,9 @@ WORKLOADS = {
 }
 
 
+TWO_KERNEL_MIN = 1024     # include/mil.h MIL_TWO_KERNEL_DEFAULT: point lights from which mil_light_ex takes k_bin -> k_shade
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -66,7 +69,7 @@ def parse():
     ap.add_argument('--gather', default='mil_mg', choices=['mil_mg', 'torch'],
                     help='N > 1: mil_mg = the multi-GPU layer of libmil.so (RCCL inside the library); torch = the Python gather '
                          '(torch.distributed P2P; the only choice for the one-GPU gloo rehearsal)')
-    ap.add_argument('--band-rows', type=int, default=32, help='mil_mg strips: rows per dealt band (0 = contiguous strips)')
+    ap.add_argument('--band-rows', type=int, default=16, help='mil_mg strips: rows per dealt band (0 = contiguous strips)')
     ap.add_argument('--chunks', type=int, default=1, help='mil_mg: launches per rank and frame (1 = best throughput: frames are enqueued back to back and the gather of frame i hides under the shading of frame i + 1; 2 = lower single-frame latency)')
     ap.add_argument('--pipelined', action='store_true',
                     help='N = 1: tonemap of frame i on a second stream beside the lighting of frame i + 1 (+3 %%; off by default so '
@@ -456,7 +459,8 @@ def run_mg(args, torch, dist, world, rank, local_rank):
                    vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'{wl}: {w}x{h} Scene A sweep, {n_dir} directional (light 0 PCF {shadow_size}^2) + {n_point} point lights'
                                         + (' + ambient' if amb else '') + ('' if strips else ', one frame per rank per step (orbiting camera, moving lights)'),
-                               kernels=['k_tiled + tonemap fused -> sRGB8 (mil_light_ex semantics inside mil_mg)'],
+                               kernels=[('k_bin -> k_order -> k_shade' if n_point >= TWO_KERNEL_MIN else 'k_tiled') +
+                                        ' + tonemap fused -> sRGB8 (mil_light_ex semantics inside mil_mg)'],
                                parallelism=(f'{world} ranks, one process per GPU; ' +
                                             (f'frame dealt in {band_rows}-row bands' if (strips and band_rows) else
                                              ('contiguous 16-row-aligned strips' if strips else 'one frame per rank')) +
@@ -472,7 +476,8 @@ def run_mg(args, torch, dist, world, rank, local_rank):
             res['config']['assembled_equals_single_gpu_bitwise'] = equal
             res['config']['note'] = ('the N = 1 default line of this bench is BASELINE.json\'s metric configuration (4K, 256 lights, two kernels): '
                                      'compare this value with config.one_gpu_same_workload, not with that line')
-        # roofline of the dominant kernel: the lighting launch over this rank's rows (k_tiled), HIP-event burst on its stream
+        # roofline of the lighting launch over this rank's rows (from 1024 point lights on: k_bin, k_order and k_shade together;
+        # k_shade is > 85 % of it), HIP-event burst on its stream
         if lrows:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for i in range(3):
@@ -487,7 +492,8 @@ def run_mg(args, torch, dist, world, rank, local_rank):
             ms = e0.elapsed_time(e1) / nb
             abytes = lrows * w * 20 + 32 * (n_dir + n_point) + 272 + (shadow_size ** 2 * 4 if shadow_size else 0)
             res['roofline'] = dict(bound='hbm', achieved=round(abytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
-                                   frac=round(abytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None, kernel='k_tiled (rank 0, its rows, fused sRGB8 store)',
+                                   frac=round(abytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None,
+                                   kernel=('k_bin + k_order + k_shade' if n_point >= TWO_KERNEL_MIN else 'k_tiled') + ' (rank 0, its rows, fused sRGB8 store)',
                                    ms=round(ms, 4), algorithmic_bytes=abytes,
                                    note='at 4096 lights the kernel is VALU-bound: see the N = 1 run of --workload cfg4_8k for the FLOP fraction')
     lp.close()
@@ -586,6 +592,8 @@ def main():
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     kname = 'k_tiled' if (inp['n_point'] or (inp['shadow_size'] and args.flags & 4)) else 'k_stream'
+    if inp['n_point'] >= TWO_KERNEL_MIN and not (args.flags & 7):
+        kname = 'k_bin+k_order+k_shade'
     if os.path.exists(tpath) and not strips:      # the PMC passes were taken on whole-frame launches
         t = json.load(open(tpath)).get(f'{args.workload}{"_fused" if args.fused else ""}:{kname}')
         if t:

@@ -701,7 +701,9 @@ int mil_shade_bands(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_da
                     const mil_frame_passes *passes, const mil_band_layout *bands, void *out, uint32_t out_pitch_px,
                     int out_is_frame, mil_out_format fmt, uint32_t flags, void *stream)
 {
-    return shade(c, gb, frame, lights, push, ex, passes ? passes : &no_passes, out, out_pitch_px, fmt, flags, stream, bands,
+    // passes == NULL is the lighting launch alone (as mil_light_ex), not a whole frame without later subpasses: the same
+    // pixels either way, but only the former may take the two-kernel form
+    return shade(c, gb, frame, lights, push, ex, passes, out, out_pitch_px, fmt, flags, stream, bands,
                  bands != nullptr && out_is_frame != 0, nullptr);
 }
 

@@ -374,8 +374,9 @@ class LightingPass:
             assert accum.dtype == t.float16 and reveal.dtype == t.float16
             fp.accum, fp.reveal = accum.data_ptr(), reveal.data_ptr()
             fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
-        return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream,
-                           bands=BandLayout(*(tuple(bands) + (0,) * (4 - len(bands)))), out_is_frame=out_is_frame)
+        # no later subpass: NULL passes = the lighting launch alone (mil_light_ex on dealt bands)
+        return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp if (sky is not None or accum is not None) else None,
+                           fmt, flags, out, stream, bands=BandLayout(*(tuple(bands) + (0,) * (4 - len(bands)))), out_is_frame=out_is_frame)
 
     def _shade(self, gb, frame, lights, point_lights, ambient, shadow, passes, fmt, flags, out, stream, bands=None,
                out_is_frame=False):
@@ -407,7 +408,7 @@ class LightingPass:
         g = self._gb(gb)
         if bands is not None:
             self._check(self.lib.mil_shade_bands(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
-                                                 ctypes.byref(ex), ctypes.byref(passes), ctypes.byref(bands), out.data_ptr(),
+                                                 ctypes.byref(ex), ctypes.byref(passes) if passes is not None else None, ctypes.byref(bands), out.data_ptr(),
                                                  pitch, 1 if out_is_frame else 0, fmt, flags, self._stream(stream)))
         elif passes is None:
             self._check(self.lib.mil_light_ex(self.ctx, ctypes.byref(g), _np_ptr(frame), _np_ptr(lights), _np_ptr(push),
