@@ -76,9 +76,15 @@ def parse():
                          'that per-kernel durations under rocprofv3 are those of kernels running alone)')
     ap.add_argument('--balance', action='store_true',
                     help='--mode strips: cut the strips by cost (wave lifetimes of one calibration frame, exchanged by one all_gather) instead of by rows')
-    ap.add_argument('--fused', action='store_true', help='one kernel: lighting + tonemap -> sRGB8 (20 B/px)')
+    ap.add_argument('--step', default='dual', choices=['dual', 'two', 'fused'],
+                    help='N = 1 step: dual = ONE launch writes the hdr image and the tonemapped sRGB8 image (mil_extras.ldr_out; default); '
+                         'two = lighting -> hdr, then the tonemap kernel -> sRGB8; fused = one launch -> sRGB8 only (no hdr image)')
+    ap.add_argument('--fused', action='store_true', help='same as --step fused')
     ap.add_argument('--flags', type=int, default=0, help='extra MIL_FLAG_* bits (experiments)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.fused:
+        args.step = 'fused'
+    return args
 
 
 def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames=64, rows=None, noise=False, all_lit=False):
@@ -99,20 +105,20 @@ def build_inputs(torch, synth, ubo, wl, device, n_sets, frame_idx=None, n_frames
                 n_dir=n_dir, n_point=n_point, shadow_size=shadow_size, rows=rows)
 
 
-def algorithmic(inp, pairs, fused, lit_px=None):
+def algorithmic(inp, pairs, mode, lit_px=None):
     """Per-launch algorithmic bytes and FLOPs of the lighting kernel.  FLOPs are counted for
     LIT pixels only (occlusion > 0): a cleared / background texel is exactly 0 whatever the lights are, and
     the kernel skips it, so counting it would flatter the VALU fraction."""
     px = inp['w'] * inp.get('lh', inp['h'])
     lit = px if lit_px is None else lit_px
-    bytes_ = px * (16 + (4 if fused else 16)) + 32 * (inp['n_dir'] + inp['n_point']) + 272
+    bytes_ = px * (16 + {'two': 16, 'dual': 20, 'fused': 4}[mode]) + 32 * (inp['n_dir'] + inp['n_point']) + 272
     if inp['shadow_size']:
         bytes_ += inp['shadow_size'] ** 2 * 4
     flops = lit * C_PIX + lit * inp['n_dir'] * C_DIR_MIN + pairs * C_POINT_MIN
     return bytes_, flops
 
 
-def kernel_burst(torch, lighting, lp, inp, n, fused, flags, which='light'):
+def kernel_burst(torch, lighting, lp, inp, n, mode, flags, which='light'):
     """Average duration of ONE kernel: n back-to-back launches (rotating buffer sets) between two HIP events
     on the stream the kernel is launched on.  An event pair around a single launch adds several microseconds of
     command-processor latency; a burst amortises it and agrees with rocprofv3's per-kernel average."""
@@ -128,12 +134,12 @@ def kernel_burst(torch, lighting, lp, inp, n, fused, flags, which='light'):
         s = i % n_sets
         if which == 'tonemap':
             lp.tonemap(hdr[s], lighting.OUT_SRGB8, out=out[s])
-        elif fused:
+        elif mode == 'fused':
             lp.light_ex(inp['sets'][s], inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_SRGB8,
                         flags=flags, out=out[s])
         else:
             lp.light_ex(inp['sets'][s], inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_HDR,
-                        flags=flags, out=hdr[s])
+                        flags=flags, out=hdr[s], ldr_out=(out[s] if mode == 'dual' else None))
     for i in range(5):
         one(i)
     torch.cuda.synchronize()
@@ -215,7 +221,7 @@ def accumulate_burst(torch, synth, lp, inp, n, n_frag):
                 hbm_GBs=round(b / ms / 1e6, 1), hbm_frac=round(b / ms / 1e6 / HBM_PEAK_GBS, 4))
 
 
-def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=None, world=1, rank=0, pipelined=True, gather=True):
+def run_workload(torch, lighting, lp, inp, steps, warmup, mode, flags, dist=None, world=1, rank=0, pipelined=True, gather=True):
     """Returns seconds for `steps` steps [max over ranks]."""
     from renderer_amd import sharding
     dev = lp.device
@@ -224,6 +230,7 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
     strips = inp.get('rows') is not None
     bounds = inp.get('bounds') or (sharding.strip_bounds(h, world) if strips else None)
     lh = (inp['rows'][1] - inp['rows'][0]) if strips else h            # rows this rank shades
+    fused = mode == 'fused'
     hdr = [None if fused else torch.empty((lh, w, 4), dtype=torch.float32, device=dev) for _ in range(n_sets)]
     out = [torch.empty((lh, w), dtype=torch.int32, device=dev) for _ in range(n_sets)]
     if strips:      # rank 0 assembles the whole frame
@@ -250,6 +257,9 @@ def run_workload(torch, lighting, lp, inp, steps, warmup, fused, flags, dist=Non
         elif fused:
             lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_SRGB8,
                         flags=flags, out=out[s])
+        elif mode == 'dual':
+            lp.light_ex(gb, inp['frame'], inp['dl'], inp['pl'], inp['amb'], inp['sh'], fmt=lighting.OUT_HDR,
+                        flags=flags, out=hdr[s], ldr_out=out[s])
         else:
             if used[s]:
                 main.wait_event(tone_done[s])            # hdr[s] is still being read by the tonemap of n_sets steps ago
@@ -570,11 +580,11 @@ def main():
     pairs = lp.count_pairs(inp['sets'][0], inp['frame'], inp['pl']) if (inp['pl'] is not None and inp.get('lh', 1)) else 0
 
     # N > 1: the gather to GPU 0 is inside the timed region (a frame counts when it is on GPU 0)
-    dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
+    dt = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.step, args.flags, dist, world, rank,
                       pipelined=(args.pipelined and world == 1), gather=True)
     dt_nogather = None
     if world > 1 and not strips:       # the same frames left on the GPUs that shaded them: what the transfer costs
-        dt_nogather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.fused, args.flags, dist, world, rank,
+        dt_nogather = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, args.step, args.flags, dist, world, rank,
                                    pipelined=False, gather=False)
     if rank != 0:
         if dist is not None:
@@ -584,9 +594,9 @@ def main():
 
     occ = (inp['sets'][0]['albedo_occ'] >> 24) & 0xFF
     lit_px = int((occ != 0).sum().item())
-    abytes, aflops = algorithmic(inp, pairs, args.fused, lit_px)
-    light_ms = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), args.fused, args.flags)
-    tone_burst_ms = 0.0 if args.fused else kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), False, 0, 'tonemap')
+    abytes, aflops = algorithmic(inp, pairs, args.step, lit_px)
+    light_ms = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), args.step, args.flags)
+    tone_burst_ms = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), 'two', 0, 'tonemap') if args.step == 'two' else 0.0
     hbm = abytes / (light_ms * 1e-3) / 1e9
     valu = aflops / (light_ms * 1e-3) / 1e12
     traffic = None
@@ -595,7 +605,7 @@ def main():
     if inp['n_point'] >= TWO_KERNEL_MIN and not (args.flags & 7):
         kname = 'k_bin+k_order+k_shade'
     if os.path.exists(tpath) and not strips:      # the PMC passes were taken on whole-frame launches
-        t = json.load(open(tpath)).get(f'{args.workload}{"_fused" if args.fused else ""}:{kname}')
+        t = json.load(open(tpath)).get(f'{args.workload}{dict(two="", dual="_dual", fused="_fused")[args.step]}:{kname}')
         if t:
             traffic = t['hbm_bytes_per_launch']
     roof_hbm = dict(bound='hbm', achieved=round(hbm, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(hbm / HBM_PEAK_GBS, 4),
@@ -617,10 +627,12 @@ def main():
                config=dict(workload=f'{args.workload}: {inp["w"]}x{inp["h"]} Scene A sweep, {inp["n_dir"]} directional '
                                     f'(light 0 PCF {inp["shadow_size"]}^2) + {inp["n_point"]} point lights'
                                     + (' + ambient' if inp['amb'] else ''),
-                           kernels=(['k_tiled+tonemap fused -> sRGB8'] if args.fused else [f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8']),
+                           kernels=dict(fused=[f'{kname} + tonemap -> sRGB8 (no hdr image)'], two=[f'{kname} -> hdr RGBA32F', 'k_tonemap -> sRGB8'],
+                                        dual=[f'{kname} -> hdr RGBA32F and, from the same registers, tonemapped sRGB8 (mil_extras.ldr_out): the lighting and '
+                                              'tonemap subpasses of render/mod.rs:201-216 + 297-309 as one pass over the pixels, both images written'])[args.step],
                            buffer_sets=args.sets, parallelism=('single GPU' if world == 1 else (f'{world} horizontal strips (16-row aligned{", cost-weighted " + str([b - a for a, b in inp["bounds"]]) if inp.get("bounds") else ""}) + P2P gather to GPU 0' if strips else f'frame-parallel x{world}, every frame gathered to GPU 0 inside the timed region')),
                            tonemap_ms=round(tone_burst_ms, 4),
-                           streams=('1 (serial)' if (not args.pipelined or args.fused or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
+                           streams=('1 (serial)' if (not args.pipelined or args.step != 'two' or world > 1) else '2: tonemap of frame i beside lighting of frame i+1'),
                            kernel_ms_method='burst of back-to-back launches between two HIP events on the launch stream'),
                roofline=primary, roofline_other=other)
     if world > 1:
@@ -634,15 +646,15 @@ def main():
     if not args.no_extra and world == 1 and args.workload == 'headline':
         # side measurement: the HBM-bound 4K / 1-light lighting pass (BASELINE.md target >= 70 % of HBM roofline)
         inp1 = build_inputs(torch, synth, ubo, 'k1_1light', dev, args.sets)
-        l1 = kernel_burst(torch, lighting, lp, inp1, max(args.steps, 20), False, 0)
-        b1, f1 = algorithmic(inp1, 0, False)
+        l1 = kernel_burst(torch, lighting, lp, inp1, max(args.steps, 20), 'two', 0)
+        b1, f1 = algorithmic(inp1, 0, 'two')
         res['extra'] = {'k1_4k_1light': dict(kernel='k_stream -> hdr RGBA32F', ms=round(l1, 4), mpix_s=round(px / l1 / 1e3, 1),
                                              hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                              algorithmic_bytes=b1)}
         del inp1
         # the same pass on Scene B (noise, every texel lit): no wave can skip anything, so this is the pure streaming rate
         inp1 = build_inputs(torch, synth, ubo, 'k1_1light', dev, args.sets, noise=True)
-        l1 = kernel_burst(torch, lighting, lp, inp1, max(args.steps, 20), False, 0)
+        l1 = kernel_burst(torch, lighting, lp, inp1, max(args.steps, 20), 'two', 0)
         res['extra']['k1_4k_1light_all_lit'] = dict(kernel='k_stream -> hdr RGBA32F, Scene B', ms=round(l1, 4), mpix_s=round(px / l1 / 1e3, 1),
                                                     hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                                     note='tools/probe/stream_probe.hip: the same four-plane access pattern with no arithmetic takes 43.6 us (6.09 TB/s), a float4 copy 41.6 us')
@@ -650,20 +662,27 @@ def main():
         # side measurement: the headline step on an ALL-LIT view of the same scene (camera pitched onto floor + spheres: no texel
         # keeps the cleared G-buffer, so nothing is skipped by the occlusion-0 early-out that covers 49 % of the headline frame)
         inpl = build_inputs(torch, synth, ubo, 'headline', dev, args.sets, all_lit=True)
-        dtl = run_workload(torch, lighting, lp, inpl, args.steps, args.warmup, False, args.flags, pipelined=False)
-        ll = kernel_burst(torch, lighting, lp, inpl, max(args.steps, 20), False, args.flags)
+        dtl = run_workload(torch, lighting, lp, inpl, args.steps, args.warmup, args.step, args.flags, pipelined=False)
+        ll = kernel_burst(torch, lighting, lp, inpl, max(args.steps, 20), args.step, args.flags)
         pairs_l = lp.count_pairs(inpl['sets'][0], inpl['frame'], inpl['pl'])
-        bl, fl = algorithmic(inpl, pairs_l, False, px)
+        bl, fl = algorithmic(inpl, pairs_l, args.step, px)
         res['extra']['headline_all_lit'] = dict(value=round(args.steps * px / dtl / 1e6, 1), unit='Mpix/s', ms_per_step=round(dtl / args.steps * 1e3, 4),
                                                 k_tiled_ms=round(ll, 4), lit_pixels=px, pairs_in_radius=pairs_l,
                                                 hbm_frac=round(bl / ll / 1e6 / HBM_PEAK_GBS, 4), valu_frac=round(fl / ll / 1e9 / VALU_PEAK_TFLOPS, 4),
-                                                note='same lights, shadow, ambient and two-kernel step as `value`; camera (7, 9, 4.5) pitched 63 degrees down')
+                                                note='same lights, shadow, ambient and step as `value`; camera (7, 9, 4.5) pitched 63 degrees down')
         del inpl
-        # side measurement: lighting + tonemap as ONE launch (hdr stays in registers; what mil_shade_frame does when the frame has
-        # no sky / transparency subpass): same output as the two-kernel step that `value` times
-        if not args.fused:
-            lf = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), True, args.flags)
-            res['extra']['headline_one_launch'] = dict(kernel='k_tiled+tonemap -> sRGB8', ms=round(lf, 4), mpix_s=round(px / lf / 1e3, 1))
+        # side measurements: the same two images by two launches (lighting -> hdr, then k_tonemap reads it back -> sRGB8), and
+        # the sRGB8 image alone by one launch (hdr stays in registers; what mil_shade_frame does)
+        if args.step == 'dual':
+            dt2 = run_workload(torch, lighting, lp, inp, args.steps, args.warmup, 'two', args.flags, pipelined=False)
+            l2 = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), 'two', args.flags)
+            t2 = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), 'two', 0, 'tonemap')
+            res['extra']['headline_two_launches'] = dict(value=round(args.steps * px / dt2 / 1e6, 1), unit='Mpix/s', ms_per_step=round(dt2 / args.steps * 1e3, 4),
+                                                         lighting_ms=round(l2, 4), tonemap_ms=round(t2, 4),
+                                                         note='the step `value` timed before mil_extras.ldr_out existed: same hdr and sRGB8 images, bit for bit')
+        if args.step != 'fused':
+            lf = kernel_burst(torch, lighting, lp, inp, max(args.steps, 20), 'fused', args.flags)
+            res['extra']['headline_one_launch'] = dict(kernel='k_tiled+tonemap -> sRGB8 only', ms=round(lf, 4), mpix_s=round(px / lf / 1e3, 1))
         # side measurement: the reference's whole frame, G-buffer -> swapchain image (render/mod.rs:189-329: lighting, sky,
         # transparency resolve, tonemap, FXAA), as the five-call chain and as mil_shade_frame + mil_fxaa (hdr never stored)
         res['extra']['frame_4k_gbuffer_to_swapchain'] = frame_chain(torch, lighting, synth, lp, inp, max(args.steps, 20))

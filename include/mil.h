@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MIL_VERSION 2
+#define MIL_VERSION 3
 #define MIL_MAX_DIR_LIGHTS 100u /* MAX_LIGHTS, renderer/shaders/inc_structs.glsl:1; pool render/pbr/mod.rs:36 */
 #define MIL_TILE 16u            /* screen tile edge of the culled path */
 
@@ -129,6 +129,14 @@ typedef struct mil_extras {
     uint32_t n_point;
     float ambient[3];                    /* E4: result += ambient * albedo * occlusion */
     const mil_shadow *shadow;            /* HOST struct, device map; NULL = off */
+    /* E6: the tonemap subpass in the same launch.  With fmt == MIL_OUT_HDR_RGBA32F the launch ALSO writes, for every pixel,
+     * what mil_tonemap(hdr, MIL_OUT_SRGB8_BGRA) makes of the value it stores to `out` (bit for bit: the same function of
+     * the same float), to this DEVICE image: the lighting draw (render/mod.rs:201-216) and the tonemap draw
+     * (render/mod.rs:297-309, fs_tonemap.glsl:14-27) as one pass over the pixels, the hdr attachment still written for
+     * the subpasses between them.  Rows as `out` (strip / dealt bands / assembled frame).  NULL = off; any other fmt:
+     * MIL_ERR_BAD_ARG. */
+    uint32_t *ldr_out;
+    uint32_t ldr_out_pitch_px;
 } mil_extras;
 
 typedef struct mil_ctx mil_ctx;

@@ -571,6 +571,7 @@ int milhost::shade_check(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matr
     if (sh && (!sh->map || sh->size == 0 || sh->size > 16384u)) return MIL_ERR_BAD_ARG;   // 32-bit texel offsets in the taps
     if (passes && passes->accum && (passes->accum_pitch_px < gb->width || passes->reveal_pitch_px < gb->width)) return MIL_ERR_BAD_ARG;
     if (out_frame && !bands) return MIL_ERR_BAD_ARG;
+    if (ex && ex->ldr_out && (fmt != MIL_OUT_HDR_RGBA32F || ex->ldr_out_pitch_px < gb->width)) return MIL_ERR_BAD_ARG;
     return MIL_OK;
 }
 
@@ -616,6 +617,10 @@ int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_dat
     if (out_frame) {    // rows of the assembled frame: the dealing's row map applies to the store too
         p.out_band_extra = p.band_extra;
         p.out = (uint8_t *)out + (size_t)p.y_offset * out_pitch_px * (fmt == MIL_OUT_HDR_RGBA32F ? 16u : 4u);
+    }
+    if (ex && ex->ldr_out) {
+        p.out2 = ex->ldr_out + (out_frame ? (size_t)p.y_offset * ex->ldr_out_pitch_px : 0);
+        p.out2_pitch = ex->ldr_out_pitch_px;
     }
     p.lut11 = c->lut;
     p.lut10 = c->lut + LUT11_N;

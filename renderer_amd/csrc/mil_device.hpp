@@ -661,6 +661,8 @@ DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t yo, f3 res, floa
     size_t o = (size_t)yo * p.out_pitch + x;
     if (FMT == FMT_HDR) {
         __builtin_nontemporal_store(v4f{ res.x, res.y, res.z, alpha }, (v4f *)p.out + o);   // fs_deferred_lighting.glsl:66
+        // the tonemap subpass of the same pixel in the same launch (mil_extras.ldr_out): what k_tonemap makes of the stored value
+        if (p.out2) __builtin_nontemporal_store(encode_ldr<FMT_SRGB8>(res.x, res.y, res.z, nullptr, nullptr), p.out2 + (size_t)yo * p.out2_pitch + x);
     } else {
         __builtin_nontemporal_store(encode_ldr<FMT>(res.x, res.y, res.z, p.lut11, p.lut10), (uint32_t *)p.out + o);
     }
@@ -668,10 +670,13 @@ DEV void store_pixel(const ShadeParams &p, uint32_t x, uint32_t yo, f3 res, floa
 // A black pixel (unlit tile) stored through pointers the caller fetched earlier: its encodings are constants
 // (ACES(0) = 0: R11G11B10F code 0, sRGB8 0xFF000000), so no uniform is read at the store.
 template <int FMT>
-DEV void store_zero(void *out, uint32_t out_pitch, uint32_t x, uint32_t y)
+DEV void store_zero(void *out, uint32_t out_pitch, uint32_t x, uint32_t y, uint32_t *out2 = nullptr, uint32_t out2_pitch = 0)
 {
     const size_t o = (size_t)y * out_pitch + x;
-    if (FMT == FMT_HDR) __builtin_nontemporal_store(v4f{ 0.0f, 0.0f, 0.0f, 1.0f }, (v4f *)out + o);
+    if (FMT == FMT_HDR) {
+        __builtin_nontemporal_store(v4f{ 0.0f, 0.0f, 0.0f, 1.0f }, (v4f *)out + o);
+        if (out2) __builtin_nontemporal_store(0xFF000000u, out2 + (size_t)y * out2_pitch + x);
+    }
     else __builtin_nontemporal_store(FMT == FMT_LDR ? 0u : 0xFF000000u, (uint32_t *)out + o);
 }
 // Whole-frame launch (FRAME, mil_shade_frame): what the later hdr-writing subpasses of the reference's render pass do
@@ -721,10 +726,14 @@ DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, RowMap rm, flo
 }
 // the same store through pointers fetched earlier (see k_tiled's unlit tiles)
 template <int FMT>
-DEV void store_pixel_to(void *out, uint32_t out_pitch, const uint8_t *lut11, const uint8_t *lut10, uint32_t x, uint32_t y, v4f h)
+DEV void store_pixel_to(void *out, uint32_t out_pitch, const uint8_t *lut11, const uint8_t *lut10, uint32_t x, uint32_t y, v4f h,
+                        uint32_t *out2 = nullptr, uint32_t out2_pitch = 0)
 {
     const size_t o = (size_t)y * out_pitch + x;
-    if (FMT == FMT_HDR) __builtin_nontemporal_store(h, (v4f *)out + o);
+    if (FMT == FMT_HDR) {
+        __builtin_nontemporal_store(h, (v4f *)out + o);
+        if (out2) __builtin_nontemporal_store(encode_ldr<FMT_SRGB8>(h.x, h.y, h.z, nullptr, nullptr), out2 + (size_t)y * out2_pitch + x);
+    }
     else __builtin_nontemporal_store(encode_ldr<FMT>(h.x, h.y, h.z, lut11, lut10), (uint32_t *)out + o);
 }
 
@@ -1071,7 +1080,9 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             const uint32_t e_out_pitch = p.out_pitch;
             uint32_t *const e_counts = p.tile_counts;
             const uint8_t *const e_lut11 = (FRAME && FMT == FMT_SRGB8_VIA_LDR) ? p.lut11 : nullptr, *const e_lut10 = (FRAME && FMT == FMT_SRGB8_VIA_LDR) ? p.lut10 : nullptr;
-            asm volatile("" :: "s"(e_out), "s"(e_out_pitch), "s"(e_counts), "s"(e_lut11), "s"(e_lut10));
+            uint32_t *const e_out2 = FMT == FMT_HDR ? p.out2 : nullptr;
+            const uint32_t e_out2_pitch = FMT == FMT_HDR ? p.out2_pitch : 0u;
+            asm volatile("" :: "s"(e_out), "s"(e_out_pitch), "s"(e_counts), "s"(e_lut11), "s"(e_lut10), "s"(e_out2), "s"(e_out2_pitch));
             if (early_depth) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.depth + i[j]), (lptr_t)(s_tex + (12 + j) * 64), 4, 0, 0);
@@ -1089,11 +1100,11 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                             h[j] = frame_value(p, x, y0 + 4 * j, rm_e, early_depth ? __uint_as_float(s_tex[(12 + j) * 64 + lane]) : 0.0f, f3{ 0.0f, 0.0f, 0.0f }, s_resolve);
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j + rm_e.o, h[j]);
+                        if (xin && (y0 + 4 * j) <= ylast) store_pixel_to<FMT>(e_out, e_out_pitch, e_lut11, e_lut10, x, y0 + 4 * j + rm_e.o, h[j], e_out2, e_out2_pitch);
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; j++)
-                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j + rm_e.o);
+                        if (xin && (y0 + 4 * j) <= ylast) store_zero<FMT>(e_out, e_out_pitch, x, y0 + 4 * j + rm_e.o, e_out2, e_out2_pitch);
                 }
                 if (e_counts && lane == 0) e_counts[tyi * k_tiles_x + txi] = 0;
                 if (k_stamps && lane == 0) {
@@ -1413,10 +1424,13 @@ DEV uint32_t cost_bucket(uint32_t len, bool brute)      // bucket 0 = most expen
     const uint32_t c = len < 32u ? (len >> 1) : 16u + min(15u, (len - 32u) >> 5);      // 16 steps of 2, then steps of 32 up to 512+
     return (MIL_WS_BUCKETS - 1u) - c;
 }
-DEV void store_zero_rt(int fmt, void *out, uint32_t out_pitch, uint32_t x, uint32_t y)
+DEV void store_zero_rt(int fmt, void *out, uint32_t out_pitch, uint32_t x, uint32_t y, uint32_t *out2, uint32_t out2_pitch)
 {
     const size_t o = (size_t)y * out_pitch + x;
-    if (fmt == FMT_HDR) __builtin_nontemporal_store(v4f{ 0.0f, 0.0f, 0.0f, 1.0f }, (v4f *)out + o);
+    if (fmt == FMT_HDR) {
+        __builtin_nontemporal_store(v4f{ 0.0f, 0.0f, 0.0f, 1.0f }, (v4f *)out + o);
+        if (out2) __builtin_nontemporal_store(0xFF000000u, out2 + (size_t)y * out2_pitch + x);
+    }
     else __builtin_nontemporal_store(fmt == FMT_LDR ? 0u : 0xFF000000u, (uint32_t *)out + o);
 }
 DEV uint32_t wave_incl_prefix(uint32_t v, uint32_t lane)
@@ -1474,7 +1488,7 @@ __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt
     // occlusion 0 multiplies every term (fs_deferred_lighting.glsl:63 and the extensions): an unlit half tile is exactly 0
 #pragma unroll
     for (int j = 0; j < 4; j++)
-        if (xin && (y0 + 4 * j) <= ylast && !(j < 2 ? anyA : anyB)) store_zero_rt(fmt, p.out, p.out_pitch, x, y0 + 4 * j + rm.o);
+        if (xin && (y0 + 4 * j) <= ylast && !(j < 2 ? anyA : anyB)) store_zero_rt(fmt, p.out, p.out_pitch, x, y0 + 4 * j + rm.o, p.out2, p.out2_pitch);
 
     // ---- boxes of the lit pixels of the two half tiles
     const float INF = __builtin_inff();

@@ -39,6 +39,8 @@ struct ShadeParams {
     const float4 *point_prep; // {position.xyz, radius^2} {color.xyz * intensity, 1/r^2}   (fast)
     const float4 *point_cull; // {position.xyz, radius}, 16 bytes per light                 (tile culling, both modes)
     uint32_t rows_per_block;  // K1: pixels per lane (1 or 4; tuning)
+    uint32_t *out2;           // HDR launches: also the tonemapped sRGB8 image of the same pixels (mil_extras.ldr_out), or null
+    uint32_t out2_pitch;
     uint32_t tune;            // experiment bits (env MIL_TUNE): 1 = K2 tile rows in plain order, 2/4 = 1/2 waves per workgroup
     float ambient[3];
     uint32_t has_ambient;

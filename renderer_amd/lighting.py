@@ -49,7 +49,8 @@ class Shadow(ctypes.Structure):            # mil_shadow
 
 class Extras(ctypes.Structure):            # mil_extras
     _fields_ = [('point_lights', ctypes.c_void_p), ('n_point', ctypes.c_uint32),
-                ('ambient', ctypes.c_float * 3), ('shadow', ctypes.POINTER(Shadow))]
+                ('ambient', ctypes.c_float * 3), ('shadow', ctypes.POINTER(Shadow)),
+                ('ldr_out', ctypes.c_void_p), ('ldr_out_pitch_px', ctypes.c_uint32)]
 
 
 class FramePasses(ctypes.Structure):      # mil_frame_passes
@@ -308,12 +309,14 @@ class LightingPass:
         return t.as_tensor(_Raw(), device=self.device)
 
     def light_ex(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, fmt=OUT_HDR,
-                 flags=0, out=None, stream=None):
-        """Lighting with the build-defined extensions, optionally fused with the tonemap."""
-        return self._shade(gb, frame, lights, point_lights, ambient, shadow, None, fmt, flags, out, stream)
+                 flags=0, out=None, stream=None, ldr_out=None):
+        """Lighting with the build-defined extensions, optionally fused with the tonemap.  ldr_out (fmt == OUT_HDR only): an
+        int32 (h, w) CUDA tensor that receives the tonemapped sRGB8 image of the same pixels in the same launch
+        (mil_extras.ldr_out)."""
+        return self._shade(gb, frame, lights, point_lights, ambient, shadow, None, fmt, flags, out, stream, ldr_out=ldr_out)
 
     def shade_frame(self, gb, frame, lights, point_lights=None, ambient=None, shadow=None, sky=None, accum=None,
-                    reveal=None, fmt=OUT_LDR, flags=0, out=None, stream=None):
+                    reveal=None, fmt=OUT_LDR, flags=0, out=None, stream=None, ldr_out=None):
         """Lighting -> sky -> transparency resolve -> tonemap (render/mod.rs:201-309) as ONE launch.
         sky: 44 floats HosekWilkieParams or None; accum (h, w, 4) / reveal (h, w) float16 or None."""
         t = self.torch
@@ -327,7 +330,7 @@ class LightingPass:
             assert accum.dtype == t.float16 and reveal.dtype == t.float16
             fp.accum, fp.reveal = accum.data_ptr(), reveal.data_ptr()
             fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
-        return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream)
+        return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp, fmt, flags, out, stream, ldr_out=ldr_out)
 
     def light_ex_noalloc(self, gb, frame, lights, point_lights_dev=None, ambient=None, shadow=None, fmt=OUT_HDR, flags=0,
                          out=None, stream=None):
@@ -359,7 +362,7 @@ class LightingPass:
         return out
 
     def shade_bands(self, gb, frame, lights, bands, point_lights=None, ambient=None, shadow=None, sky=None, accum=None,
-                    reveal=None, fmt=OUT_LDR, flags=0, out=None, out_is_frame=False, stream=None):
+                    reveal=None, fmt=OUT_LDR, flags=0, out=None, out_is_frame=False, stream=None, ldr_out=None):
         """mil_shade_bands: mil_shade_frame on a rank's dealt bands.  gb: the rank's compacted planes with width / height
         of the WHOLE frame in gb['width'] / gb['height']; bands = (band_rows, n_ranks, rank[, first_band]).  out: the rank's compacted
         output, or (out_is_frame) the assembled frame."""
@@ -376,10 +379,11 @@ class LightingPass:
             fp.accum_pitch_px, fp.reveal_pitch_px = accum.stride(0) // 4, reveal.stride(0)
         # no later subpass: NULL passes = the lighting launch alone (mil_light_ex on dealt bands)
         return self._shade(gb, frame, lights, point_lights, ambient, shadow, fp if (sky is not None or accum is not None) else None,
-                           fmt, flags, out, stream, bands=BandLayout(*(tuple(bands) + (0,) * (4 - len(bands)))), out_is_frame=out_is_frame)
+                           fmt, flags, out, stream, bands=BandLayout(*(tuple(bands) + (0,) * (4 - len(bands)))), out_is_frame=out_is_frame,
+                           ldr_out=ldr_out)
 
     def _shade(self, gb, frame, lights, point_lights, ambient, shadow, passes, fmt, flags, out, stream, bands=None,
-               out_is_frame=False):
+               out_is_frame=False, ldr_out=None):
         t = self.torch
         h, w = gb['depth'].shape
         lights = np.ascontiguousarray(lights if lights is not None else np.zeros((0, 8)), np.float32).reshape(-1, 8)
@@ -400,6 +404,9 @@ class LightingPass:
                         sm.shape[0], float(shadow['bias']))
             keep.append(sh)
             ex.shadow = ctypes.pointer(sh)
+        if ldr_out is not None:
+            assert ldr_out.is_cuda and ldr_out.dtype == t.int32 and ldr_out.stride(1) == 1
+            ex.ldr_out, ex.ldr_out_pitch_px = ldr_out.data_ptr(), ldr_out.stride(0)
         if out is None:
             oh = gb['height'] if out_is_frame else h
             out = (t.empty((oh, w, 4), dtype=t.float32, device=self.device) if fmt == OUT_HDR

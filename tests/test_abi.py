@@ -25,7 +25,7 @@ def test_header_symbols_are_exported():
     assert sorted(syms) == sorted(lighting.EXPORTS + multigpu.EXPORTS)
     for s in syms:
         assert hasattr(lib, s), s
-    assert lib.mil_version() == 2
+    assert lib.mil_version() == 3
     assert lib.mil_strerror(0) == b'ok' and b'bad argument' in lib.mil_strerror(-1)
 
 
@@ -33,7 +33,7 @@ def test_struct_layouts_match_reference():
     # mil_gbuffer / mil_shadow / mil_extras as the ctypes mirror sees them
     assert ctypes.sizeof(lighting.GBuffer) == 48
     assert ctypes.sizeof(lighting.Shadow) == 80
-    assert ctypes.sizeof(lighting.Extras) == 32
+    assert ctypes.sizeof(lighting.Extras) == 48       # v3: + ldr_out, ldr_out_pitch_px
     # reference blocks (render/ubo.rs:28-63, fs_deferred_lighting.glsl:16-27)
     assert ubo.frame_matrix_data(np.eye(4), np.eye(4), (1, 2, 3)).nbytes == ubo.FRAME_UBO_BYTES == 272
     f = ubo.frame_matrix_data(np.eye(4), np.eye(4), (1, 2, 3))
