@@ -364,10 +364,14 @@ template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T Ld
     // alpha / ((1-x2) + x2*alpha^2), the denominator rewritten as x2*(alpha^2-1) + 1.  For a mirror-like texel (roughness
     // byte <= 3) alpha^2 - 1 rounds to -1 and the rewritten form is 0 at N.H = 1 (the literal form gives alpha^2 there):
     // clamped to that true minimum
-    T k = q.alpha * rcp_(max_(fma_(x2, q.am1, (T)1.0f), q.a2));
+    T t = max_(fma_(x2, q.am1, (T)1.0f), q.a2);
     T sL = sqrt_(fma_(fma_(-q.a2, NdotL, NdotL), NdotL, q.a2));
     T den = fma_(NdotL, q.sV, q.NdotV * sL);                             // GGXV + GGXL
-    T DV = (k * k) * ((0.5f / PI_LIT) * rcp_(den));                      // D * Vis
+    // D * Vis = (alpha / t)^2 * 0.5 / (pi den) with ONE reciprocal (a quarter-rate instruction: 16 cycles a wave against 4):
+    // u = alpha / (t den), D * Vis = u * (u * den * 0.5 / pi).  t den >= alpha^2 * N.V alpha >= 1e-28 and the product is
+    // formed small-to-large, so nothing under- or overflows that the two-reciprocal form kept finite.
+    T u = q.alpha * rcp_(t * den);
+    T DV = u * (u * (den * (0.5f / PI_LIT)));                            // D * Vis
     T w = 1.0f - LdotH, w2 = w * w, w5 = w2 * w2 * w;
     T cx = fma_(fma_(q.G1.x, w5, q.G0.x), DV, q.dif.x);
     T cy = fma_(fma_(q.G1.y, w5, q.G0.y), DV, q.dif.y);
@@ -444,6 +448,27 @@ DEV v2f point_d2_2(const Px2 &q, v4f a, V3<v2f> &Lv)
 {
     Lv = V3<v2f>{ a.x - q.P.x, a.y - q.P.y, a.z - q.P.z };
     return fma_(Lv.z, Lv.z, fma_(Lv.y, Lv.y, Lv.x * Lv.x));
+}
+// Which lanes' pixels are within the light's radius, as two wave masks formed on the scalar side: the compares write SGPR
+// pairs, the "anybody?" test is one s_or + s_cmp, and the per-lane select in point_eval2 reads the masks back (inverse
+// ballot: no instruction).  Written with bools, the compiler materialised the ballot argument through v_cndmask +
+// v_cmp_ne, and the "pixel is lit" half of the condition through two more compares per light: 4 of the 15 VALU
+// instructions a tested-and-rejected light cost.  The lit half now sits in the data: before a point-light loop an unlit
+// pixel's position is moved out of every light's reach (far_if_unlit), so the distance compare alone rejects it.
+struct PointMasks { unsigned long long m0, m1; };
+DEV PointMasks point_masks(v2f d2, float r2)
+{
+    return PointMasks{ __builtin_amdgcn_ballot_w64(d2.x < r2), __builtin_amdgcn_ballot_w64(d2.y < r2) };
+}
+// |P - c|^2 overflows to +inf for every light (never < r^2); should such a lane ride along in point_eval2 (another lane's
+// pixel is in range), its L = Lv * rsq(inf) = -0, every BRDF term stays finite and its radiance is selected to 0:
+// an unlit pixel's sum stays exactly 0, as before.
+DEV void far_if_unlit(Px2 &q)
+{
+    const bool a = q.occ.x > 0.0f, b = q.occ.y > 0.0f;
+    q.P.x = v2f{ a ? q.P.x.x : 1e30f, b ? q.P.x.y : 1e30f };
+    q.P.y = v2f{ a ? q.P.y.x : 1e30f, b ? q.P.y.y : 1e30f };
+    q.P.z = v2f{ a ? q.P.z.x : 1e30f, b ? q.P.z.y : 1e30f };
 }
 DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1, V3<v2f> &res)
 {
@@ -853,12 +878,14 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
     }
     for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, sh && l == 0, r);   // fs_deferred_lighting.glsl:62-64
     if (EXT) {
+        far_if_unlit(q);
         for (uint32_t l = 0; l < p.n_point; l++) {
             const v4f a = point_rec_a(p, l);
             V3<v2f> Lv;
             const v2f d2 = point_d2_2(q, a, Lv);
-            const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
-            if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;
+            const PointMasks pm = point_masks(d2, a.w);
+            if ((pm.m0 | pm.m1) == 0) continue;
+            const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
             point_eval2(q, point_rec_b(p, l), Lv, d2, on0, on1, r);
         }
         if (p.has_ambient) {
@@ -1280,7 +1307,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 uint32_t kb = 0;
 #pragma unroll 1
                 for (;;) {
-                    const uint32_t n = min(64u, cnt - kb);
+                    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, cnt - kb));      // scalar loop bound
 #pragma unroll 1
                     for (uint32_t k = 0; k < n; k++) {
                         const v4f a = bcast4(ra, (int)k);
@@ -1343,17 +1370,19 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 r.z = v2f{ s_res[512 + ja * 64 + lane], s_res[512 + (ja + 1) * 64 + lane] };
             }
             if (cnt) {
+                far_if_unlit(q);
                 uint32_t kb = 0;
 #pragma unroll 1
                 for (;;) {
-                    const uint32_t n = min(64u, cnt - kb);
+                    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, cnt - kb));      // scalar loop bound
 #pragma unroll 1
                     for (uint32_t k = 0; k < n; k++) {
                         const v4f a = bcast4(ra, (int)k);
                         V3<v2f> Lv;
                         const v2f d2 = point_d2_2(q, a, Lv);
-                        const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
-                        if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;   // wave-uniform: nobody in range
+                        const PointMasks pm = point_masks(d2, a.w);
+                        if ((pm.m0 | pm.m1) == 0) continue;   // wave-uniform: nobody in range
+                        const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
                         point_eval2(q, bcast4(rb, (int)k), Lv, d2, on0, on1, r);
                     }
                     kb += 64;
@@ -1684,18 +1713,20 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
         if (litB) shadow.y = pcf_direct(tb, p);
     }
     for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
+    far_if_unlit(q);
     if (len) {
         uint32_t kb = 0;
 #pragma unroll 1
         for (;;) {
-            const uint32_t n = min(64u, len - kb);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, len - kb));      // scalar loop bound
 #pragma unroll 1
             for (uint32_t k = 0; k < n; k++) {
                 const v4f a = bcast4(ra, (int)k);
                 V3<v2f> Lv;
                 const v2f d2 = point_d2_2(q, a, Lv);
-                const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
-                if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;       // wave-uniform: nobody in range
+                const PointMasks pm = point_masks(d2, a.w);
+                if ((pm.m0 | pm.m1) == 0) continue;       // wave-uniform: nobody in range
+                const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
                 point_eval2(q, bcast4(rb, (int)k), Lv, d2, on0, on1, r);
             }
             kb += 64;
@@ -1708,8 +1739,9 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
             const v4f a = point_rec_a(p, l);
             V3<v2f> Lv;
             const v2f d2 = point_d2_2(q, a, Lv);
-            const bool on0 = d2.x < a.w && q.occ.x > 0.0f, on1 = d2.y < a.w && q.occ.y > 0.0f;
-            if (__builtin_amdgcn_ballot_w64(on0 || on1) == 0) continue;
+            const PointMasks pm = point_masks(d2, a.w);
+            if ((pm.m0 | pm.m1) == 0) continue;
+            const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
             point_eval2(q, point_rec_b(p, l), Lv, d2, on0, on1, r);
         }
     }
