@@ -47,6 +47,7 @@ WORKLOADS = {
     'k1_1light': (3840, 2160, 1, 0, 0, False),
     'cfg2_1080p': (1920, 1080, 1, 0, 2048, False),
     'cfg4_8k': (7680, 4320, 2, 4096, 2048, True),
+    'valu_4k_4096': (3840, 2160, 2, 4096, 2048, True),      # north_star: the 4K / 4096-light pass (FP32 VALU target)
 }
 
 
@@ -659,6 +660,18 @@ def main():
                                                     hbm_GBs=round(b1 / l1 / 1e6, 1), hbm_frac=round(b1 / l1 / 1e6 / HBM_PEAK_GBS, 4),
                                                     note='tools/probe/stream_probe.hip: the same four-plane access pattern with no arithmetic takes 43.6 us (6.09 TB/s), a float4 copy 41.6 us')
         del inp1
+        # side measurement: the VALU-bound 4K / 4096-light lighting pass (north_star target >= 50 % of FP32 VALU peak): k_bin ->
+        # k_order -> k_shade, hdr out.  The FLOP fraction is quoted against the spec peak and against the packed-FMA rate
+        # measured on this part (tools/probe: 4.8 cycles per dependent v_pk_fma_f32 at 4 waves per SIMD -> 131 TFLOP/s)
+        inpv = build_inputs(torch, synth, ubo, 'valu_4k_4096', dev, args.sets)
+        lv = kernel_burst(torch, lighting, lp, inpv, max(args.steps // 2, 10), 'two', args.flags)
+        pairs_v = lp.count_pairs(inpv['sets'][0], inpv['frame'], inpv['pl'])
+        occ_v = (inpv['sets'][0]['albedo_occ'] >> 24) & 0xFF
+        bv, fv = algorithmic(inpv, pairs_v, 'two', int((occ_v != 0).sum().item()))
+        res['extra']['k2_4k_4096'] = dict(kernel='k_bin + k_order + k_shade -> hdr RGBA32F', ms=round(lv, 4), mpix_s=round(px / lv / 1e3, 1),
+                                          pairs_in_radius=pairs_v, algorithmic_flops=fv, tflops=round(fv / lv / 1e9, 2),
+                                          valu_frac=round(fv / lv / 1e9 / VALU_PEAK_TFLOPS, 4), valu_frac_of_measured_131tf=round(fv / lv / 1e9 / 131.0, 4))
+        del inpv, occ_v
         # side measurement: the headline step on an ALL-LIT view of the same scene (camera pitched onto floor + spheres: no texel
         # keeps the cleared G-buffer, so nothing is skipped by the occlusion-0 early-out that covers 49 % of the headline frame)
         inpl = build_inputs(torch, synth, ubo, 'headline', dev, args.sets, all_lit=True)

@@ -39,8 +39,8 @@ for (case, k), cs in sorted(agg.items()):
         # gfx950 -> x2; WRITE_SIZE (KiB) is exact for 16-B-per-lane streaming stores.
         rd, wr = 2 * m['FETCH_SIZE'] * 1024, m['WRITE_SIZE'] * 1024
         out.append(f'   -> HBM bytes/launch: read {rd/1e6:.1f} MB (2 x FETCH_SIZE), write {wr/1e6:.1f} MB, total {(rd+wr)/1e6:.1f} MB')
-        kn = 'k_tiled' if 'k_tiled' in k else ('k_stream' if 'k_stream' in k else k.split('::')[-1])
-        wl = {'headline': 'headline', 'k1': 'k1_1light', 'accumulate': 'accumulate_4k_layer'}[case]
+        kn = 'k_tiled' if 'k_tiled' in k else ('k_stream' if 'k_stream' in k else ('k_shade' if 'k_shade' in k else k.split('::')[-1]))
+        wl = {'headline': 'headline', 'dual': 'headline_dual', 'l4096': 'valu_4k_4096', 'k1': 'k1_1light', 'accumulate': 'accumulate_4k_layer'}[case]
         traffic[f'{wl}:{kn}'] = dict(hbm_bytes_per_launch=int(rd + wr), fetch_size_kib=m['FETCH_SIZE'], write_size_kib=m['WRITE_SIZE'],
                                      note='read = 2 x FETCH_SIZE KiB (gfx950 correction, MI355X_MICROARCH.md HBM), write = WRITE_SIZE KiB')
 open(f'{O}/summary_{R}.txt', 'w').write('\n'.join(out) + '\n')

@@ -9,11 +9,11 @@ O=gpurun_out/prof_$R
 mkdir -p $O
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
 for c in FETCH_SIZE WRITE_SIZE; do
-  for k in headline k1 accumulate; do
+  for k in headline dual l4096 k1 accumulate; do
     timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${k}_$c -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_$c.log 2>&1
   done
 done
-for k in headline k1; do
+for k in headline dual l4096 k1; do
   timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $O/pmc_${k}_SQ -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_SQ.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${k}_GRBM -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_GRBM.log 2>&1
 done

@@ -10,7 +10,7 @@ lp = lighting.LightingPass(0, 4096)
 cam = synth.sweep_camera(W, H)
 gbs = [synth.scene_sweep(W, H, cam, device=dev)]
 for _ in range(2): gbs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in gbs[0].items()})
-frame = cam.frame_matrix_data(); dl = ubo.default_directional_lights(); pl = synth.point_light_field(int(os.environ.get('NPT', '256')), 0x5EED0003)
+frame = cam.frame_matrix_data(); dl = ubo.default_directional_lights(); pl = synth.point_light_field(4096 if case == 'l4096' else int(os.environ.get('NPT', '256')), 0x5EED0003)
 sh = synth.shadow_setup(dl[0, :3], 2048, device=dev); amb = (0.03,) * 3
 hdrs = [torch.empty((H, W, 4), device=dev) for _ in range(3)]
 outs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(3)]
@@ -25,7 +25,8 @@ for i in range(iters):
     k = i % 3
     if case == 'k1': lp.light_directional(gbs[k], frame, dl[:1], out=hdrs[k])
     elif case == 'k1_2': lp.light_directional(gbs[k], frame, dl, out=hdrs[k])
-    elif case == 'headline': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, out=hdrs[k])
+    elif case in ('headline', 'l4096'): lp.light_ex(gbs[k], frame, dl, pl, amb, sh, out=hdrs[k])      # l4096: run with NPT=4096
+    elif case == 'dual': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, out=hdrs[k], ldr_out=outs[k])
     elif case == 'headline_lds': lp.light_ex(gbs[k], frame, dl, pl, amb, sh, flags=4, out=hdrs[k])
     elif case == 'hl_noshadow': lp.light_ex(gbs[k], frame, dl, pl, amb, None, out=hdrs[k])
     elif case == 'hl_nopoints': lp.light_ex(gbs[k], frame, dl, None, amb, sh, flags=4, out=hdrs[k])
