@@ -512,8 +512,21 @@ def run_mg(args, torch, dist, world, rank, local_rank):
     return res
 
 
+def emit(res, saved_stdout):
+    """The ONE line of stdout."""
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(res), flush=True)
+    os.dup2(2, 1)
+
+
 def main():
     args = parse()
+    # stdout carries exactly one JSON line: everything else that lands on file descriptor 1 while the bench runs (RCCL prints a
+    # version banner there when a communicator is created, inside torch as well as inside libmil) goes to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     from renderer_amd import lighting, synth, ubo
 
@@ -544,7 +557,7 @@ def main():
     if (world > 1 or force_mg) and args.gather == 'mil_mg' and not rehearse:
         res = run_mg(args, torch, dist, world, rank, local_rank)
         if rank == 0:
-            print(json.dumps(res))
+            emit(res, saved_stdout)
         dist.barrier()
         dist.destroy_process_group()
         return
@@ -703,7 +716,7 @@ def main():
         res['extra']['transparency_accumulate_4k_layer'] = accumulate_burst(torch, synth, lp, inp, max(args.steps, 20), px)
     if not args.no_cpu and world == 1:
         res['cpu_baseline'] = cpu_baseline(inp)
-    print(json.dumps(res))
+    emit(res, saved_stdout)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
