@@ -502,11 +502,25 @@ def run_mg(args, torch, dist, world, rank, local_rank):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / nb
             abytes = lrows * w * 20 + 32 * (n_dir + n_point) + 272 + (shadow_size ** 2 * 4 if shadow_size else 0)
-            res['roofline'] = dict(bound='hbm', achieved=round(abytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+            hbm_roof = dict(bound='hbm', achieved=round(abytes / ms / 1e6, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                                    frac=round(abytes / ms / 1e6 / HBM_PEAK_GBS, 4), traffic=None,
                                    kernel=('k_bin + k_order + k_shade' if n_point >= TWO_KERNEL_MIN else 'k_tiled') + ' (rank 0, its rows, fused sRGB8 store)',
                                    ms=round(ms, 4), algorithmic_bytes=abytes,
-                                   note='at 4096 lights the kernel is VALU-bound: see the N = 1 run of --workload cfg4_8k for the FLOP fraction')
+                                   )
+            res['roofline'] = hbm_roof
+            if strips and n_point:
+                # FLOPs of the WHOLE frame (pairs counted on rank 0's copy of it) / world: the bands are dealt evenly
+                gbf = dict(gb_full, y_offset=0)
+                pairs = lp.count_pairs(gbf, frame, pl)
+                lit = int((((gb_full['albedo_occ'] >> 24) & 0xFF) != 0).sum().item())
+                flops = (lit * C_PIX + lit * n_dir * C_DIR_MIN + pairs * C_POINT_MIN) / world
+                valu_roof = dict(bound='valu', achieved=round(flops / ms / 1e9, 2), peak=VALU_PEAK_TFLOPS, unit='TFLOP/s',
+                                 frac=round(flops / ms / 1e9 / VALU_PEAK_TFLOPS, 4), traffic=None, kernel=hbm_roof['kernel'], ms=round(ms, 4),
+                                 algorithmic_flops=int(flops), note='FLOPs of the whole frame / ranks (bands dealt evenly), lit pixels only')
+                if valu_roof['frac'] > hbm_roof['frac']:
+                    res['roofline'], res['roofline_other'] = valu_roof, hbm_roof
+                else:
+                    res['roofline_other'] = valu_roof
     lp.close()
     mg.close()
     return res
