@@ -12,6 +12,7 @@ gbs = [synth.scene_sweep(W, H, cam, device=dev)]
 for _ in range(2): gbs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in gbs[0].items()})
 frame = cam.frame_matrix_data(); dl = ubo.default_directional_lights(); pl = synth.point_light_field(4096 if case == 'l4096' else int(os.environ.get('NPT', '256')), 0x5EED0003)
 sh = synth.shadow_setup(dl[0, :3], 2048, device=dev); amb = (0.03,) * 3
+far = pl.copy(); far[:, 0:3] += 1.0e4; far1 = far[:1]      # point lights far outside the scene (budget cases)
 hdrs = [torch.empty((H, W, 4), device=dev) for _ in range(3)]
 outs = [torch.empty((H, W), dtype=torch.int32, device=dev) for _ in range(3)]
 frs = None
@@ -32,6 +33,8 @@ for i in range(iters):
     elif case == 'hl_nopoints': lp.light_ex(gbs[k], frame, dl, None, amb, sh, flags=4, out=hdrs[k])
     elif case == 'hl_nodir': lp.light_ex(gbs[k], frame, dl[:0], pl, amb, None, out=hdrs[k])
     elif case == 'points': lp.light_ex(gbs[k], frame, dl[:0], pl, None, None, out=hdrs[k])
+    elif case == 'b_base': lp.light_ex(gbs[k], frame, dl[:0], far1, None, None, out=hdrs[k])       # k_tiled with nothing to add: loads, box, two setups, stores
+    elif case == 'b_cull': lp.light_ex(gbs[k], frame, dl[:0], far, None, None, out=hdrs[k])        # + culling NPT lights that reach nothing
     elif case == 'tonemap': lp.tonemap(hdrs[k], 2, out=outs[k])
     elif case == 'fxaa': lp.fxaa(ldrs[k], out=outs[k])
     elif case == 'accumulate': lp.transparency_accumulate(frs[i % 2], frame, dl, accum=acc[i % 2], reveal=rev[i % 2])
