@@ -475,7 +475,7 @@ def run_mg(args, torch, dist, world, rank, local_rank):
                                parallelism=(f'{world} ranks, one process per GPU; ' +
                                             (f'frame dealt in {band_rows}-row bands' if (strips and band_rows) else
                                              ('contiguous 16-row-aligned strips' if strips else 'one frame per rank')) +
-                                            f', {args.chunks} chunks per rank, grouped ncclSend/ncclRecv to GPU 0 per chunk on a second stream'),
+                                            f', {args.chunks} chunks per rank, grouped ncclSend/ncclRecv to GPU 0 per chunk on a second stream (dealt bands: one message per rank into a staging slice, scattered into the frame by a strided copy)'),
                                gather='inside the timed region: `value` counts a frame when it is assembled on GPU 0',
                                gather_path='libmil mil_mg (RCCL bound inside the library)', rccl_ranks=rccl_ranks,
                                shading_only=dict(value=round(args.steps * total_px / dt_shade / 1e6, 1), unit='Mpix/s',

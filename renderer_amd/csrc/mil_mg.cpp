@@ -83,6 +83,9 @@ struct mil_mg {
     std::vector<Local> locals;
     int rccl_error = 0, last_hip = 0, rccl_ranks = 0;
     bool single_process = false;
+    // rank 0's device: where the dealt rows of the other ranks land before they are scattered into the frame (one slice per rank)
+    uint8_t *stage = nullptr;
+    size_t stage_slice = 0;
 };
 
 namespace {
@@ -216,14 +219,31 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
         if (dst_pitch_px != r.gb.width && !(in_place[i] && dst_pitch_px > r.gb.width && m->world == 1)) return MIL_ERR_BAD_ARG;
     }
 
+    // ---- dealt bands travel as ONE message per rank and chunk (the sender's rows are contiguous) into a staging slice on
+    // rank 0's device and are scattered into the frame there by a strided copy: 34 messages of 491 KB per rank and 8K frame
+    // (16-row bands) would each pay the point-to-point set-up on the one channel a peer pair uses.  Contiguous strips and
+    // whole frames have one piece and are received in place.
+    uint32_t max_rows = 0;
+    for (int r = 0; r < m->world; r++) max_rows = plan[r].rows > max_rows ? plan[r].rows : max_rows;
+    const size_t row_bytes = (size_t)push->resolution[0] * bpp;
+    const bool staged = strips && m->cfg.band_rows != 0;
+    if (staged && root && (size_t)max_rows * row_bytes > m->stage_slice) {
+        MG_HIP(m, hipSetDevice(root->device));
+        MG_HIP(m, hipStreamSynchronize(root->gather));
+        if (m->stage) { MG_HIP(m, hipFree(m->stage)); m->stage = nullptr; m->stage_slice = 0; }
+        MG_HIP(m, hipMalloc((void **)&m->stage, (size_t)max_rows * row_bytes * m->world));
+        m->stage_slice = (size_t)max_rows * row_bytes;
+    }
+
     // ---- enqueue, chunk by chunk
     std::vector<Piece> part;
+    struct Scatter { int rank; uint32_t k0, k1; };
+    std::vector<Scatter> scatter;
     for (Local &l : m->locals)                                  // the previous frame's gather must have left the output buffers
         if (l.gathered_valid) {
             MG_HIP(m, hipSetDevice(l.device));
             MG_HIP(m, hipStreamWaitEvent(l.compute, l.gathered, 0));
         }
-    const size_t row_bytes = (size_t)push->resolution[0] * bpp;
     for (size_t c = 0; c < n_chunks; c++) {
         // shade chunk c on every local rank
         for (size_t i = 0; i < m->locals.size(); i++) {
@@ -269,6 +289,26 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
             if (!src && !root) continue;                                // neither end lives in this process
             const Plan &pl = plan[r];
             if (c + 1 >= pl.cuts.size()) continue;
+            if (staged) {                                               // one message, scattered on rank 0 after the group
+                const uint32_t k0 = pl.cuts[c], k1 = pl.cuts[c + 1];
+                const size_t n = (size_t)(k1 - k0) * row_bytes;
+                uint8_t *d = root ? m->stage + (size_t)r * m->stage_slice + (size_t)k0 * row_bytes : nullptr;
+                const uint8_t *sp = src ? (const uint8_t *)io[si].out + (size_t)k0 * row_bytes : nullptr;
+                if (err != MIL_OK) continue;
+                if (use_rccl) {
+                    if (src) { const ncclResult_t e = rccl().Send(sp, n, ncclChar, 0, src->comm, src->gather); if (e != ncclSuccess) err = ncclf(m, e); }
+                    if (root && err == MIL_OK) { const ncclResult_t e = rccl().Recv(d, n, ncclChar, r, root->comm, root->gather); if (e != ncclSuccess) err = ncclf(m, e); }
+                } else if (src && root) {
+                    // the emulation's sender stream carries the copy; the scatter below runs on rank 0's gather stream behind it
+                    hipError_t e = hipSetDevice(src->device);
+                    if (e == hipSuccess) e = hipMemcpyAsync(d, sp, n, hipMemcpyDeviceToDevice, src->gather);
+                    if (e == hipSuccess) e = hipEventRecord(src->chunk_done[m->locals[si].chunk_done.size() - 1], src->gather);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(root->gather, src->chunk_done[m->locals[si].chunk_done.size() - 1], 0);
+                    if (e != hipSuccess) err = hipf(m, e);
+                }
+                if (root && err == MIL_OK) scatter.push_back(Scatter{ r, k0, k1 });
+                continue;
+            }
             pieces_in(pl.pieces, pl.cuts[c], pl.cuts[c + 1], part);
             for (const Piece &p : part) {
                 const size_t n = (size_t)p.rows * row_bytes;
@@ -290,6 +330,25 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
             if (e != ncclSuccess && err == MIL_OK) err = ncclf(m, e);
         }
         if (err) return err;
+        // staging slice -> frame rows, on rank 0's gather stream behind the receives: runs of whole bands as one strided copy
+        if (!scatter.empty()) MG_HIP(m, hipSetDevice(root->device));
+        for (const Scatter &sc : scatter) {
+            pieces_in(plan[sc.rank].pieces, sc.k0, sc.k1, part);
+            const uint8_t *base = m->stage + (size_t)sc.rank * m->stage_slice;
+            const uint32_t B = m->cfg.band_rows, stride = B * (uint32_t)m->world;
+            size_t i = 0;
+            while (i < part.size()) {
+                size_t j = i + 1;
+                if (part[i].rows == B)
+                    while (j < part.size() && part[j].rows == B && part[j].frame0 == part[j - 1].frame0 + stride && part[j].local0 == part[j - 1].local0 + B) j++;
+                uint8_t *d = (uint8_t *)dst_of[sc.rank] + (size_t)part[i].frame0 * row_bytes;
+                const uint8_t *sp = base + (size_t)part[i].local0 * row_bytes;
+                if (j - i > 1) MG_HIP(m, hipMemcpy2DAsync(d, (size_t)stride * row_bytes, sp, (size_t)B * row_bytes, (size_t)B * row_bytes, j - i, hipMemcpyDeviceToDevice, root->gather));
+                else MG_HIP(m, hipMemcpyAsync(d, sp, (size_t)part[i].rows * row_bytes, hipMemcpyDeviceToDevice, root->gather));
+                i = j;
+            }
+        }
+        scatter.clear();
     }
     for (Local &l : m->locals) {
         MG_HIP(m, hipSetDevice(l.device));
@@ -329,6 +388,10 @@ void mil_mg_destroy(mil_mg *m)
         if (l.compute) (void)hipStreamDestroy(l.compute);
         if (l.gather) (void)hipStreamDestroy(l.gather);
         if (l.ctx) mil_destroy(l.ctx);
+    }
+    if (m->stage) {
+        for (Local &l : m->locals) if (l.rank == 0) (void)hipSetDevice(l.device);
+        (void)hipFree(m->stage);
     }
     delete m;
 }
