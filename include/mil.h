@@ -382,7 +382,12 @@ typedef struct mil_mg_rank_io {
 
 /* ONE frame over all ranks (replaces render/mod.rs:201-216 + :297-309 for N devices): rank r shades its rows with
  * mil_light_ex semantics (lighting fused with the encode of fmt) and the rows are gathered into `full` on rank 0's device
- * (whole frame, dense; ignored by processes that do not drive rank 0).  push->resolution = the whole frame. */
+ * (whole frame, dense; ignored by processes that do not drive rank 0).  push->resolution = the whole frame.
+ * The call returns when the work is enqueued (mil_mg_sync waits).  Calls may follow one another without a sync: a frame
+ * waits for the transfers of an earlier frame only when it writes a buffer (io[].out, full, a slot) that frame used, so a
+ * caller that rotates its buffers has the gather of frame i running under the shading of frame i + 1; up to four frames are
+ * tracked.  Dealt bands are received into a staging area the handle allocates on rank 0's device when the first frame (or a
+ * larger one) is rendered - the only allocation of a per-frame call - and scattered into `full` from there. */
 int mil_mg_render_strips(mil_mg *mg, const mil_mg_rank_io *io, const mil_frame_matrix_data *frame,
                          const mil_directional_light *lights, const mil_push_constants *push, mil_out_format fmt,
                          uint32_t flags, void *full, uint32_t full_pitch_px);

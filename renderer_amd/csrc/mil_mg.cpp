@@ -71,8 +71,15 @@ struct Local {                      // one rank this process drives
     hipStream_t compute = nullptr, gather = nullptr;
     ncclComm_t comm = nullptr;
     std::vector<hipEvent_t> chunk_done;      // compute -> gather, one per chunk
-    hipEvent_t gathered = nullptr;           // gather stream: the rank's previous frame has left its output buffer
-    bool gathered_valid = false;
+    // The last FRAMES_IN_FLIGHT frames of this rank: an event on the gather stream behind the frame's last transfer, and the
+    // buffers the frame's shading wrote / its transfers read or wrote.  A new frame waits only for earlier frames that touch
+    // one of ITS buffers: a caller that rotates its output buffers gets the gather of frame i under the shading of frame
+    // i + 1; a caller that reuses one buffer gets them one after the other.
+    static constexpr int FRAMES_IN_FLIGHT = 4;
+    hipEvent_t gathered[FRAMES_IN_FLIGHT] = {};
+    std::vector<const void *> touched[FRAMES_IN_FLIGHT];
+    bool gathered_valid[FRAMES_IN_FLIGHT] = {};
+    int frame_next = 0;
 };
 
 } // namespace
@@ -164,7 +171,7 @@ int create_common(mil_mg *m, const mil_mg_config *cfg)
         // (GPU_MAX_HW_QUEUES) mixed-priority streams stopped making progress, so every chunk runs on the one stream.)
         MG_HIP(m, hipStreamCreateWithFlags(&l.compute, hipStreamNonBlocking));
         MG_HIP(m, hipStreamCreateWithFlags(&l.gather, hipStreamNonBlocking));
-        MG_HIP(m, hipEventCreateWithFlags(&l.gathered, hipEventDisableTiming));
+        for (hipEvent_t &e : l.gathered) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const uint32_t n = cfg->chunks ? cfg->chunks : 4u;
         l.chunk_done.resize(n + 1);
         for (hipEvent_t &e : l.chunk_done) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -239,11 +246,25 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
     std::vector<Piece> part;
     struct Scatter { int rank; uint32_t k0, k1; };
     std::vector<Scatter> scatter;
-    for (Local &l : m->locals)                                  // the previous frame's gather must have left the output buffers
-        if (l.gathered_valid) {
-            MG_HIP(m, hipSetDevice(l.device));
-            MG_HIP(m, hipStreamWaitEvent(l.compute, l.gathered, 0));
+    // an earlier frame's transfers must have left the buffers this frame writes (see Local::touched)
+    for (size_t i = 0; i < m->locals.size(); i++) {
+        Local &l = m->locals[i];
+        std::vector<const void *> mine;
+        if (io[i].out) mine.push_back(io[i].out);
+        if (l.rank == 0) for (int r = 0; r < m->world; r++) mine.push_back(dst_of[r]);
+        MG_HIP(m, hipSetDevice(l.device));
+        const int slot = l.frame_next;
+        for (int k = 0; k < Local::FRAMES_IN_FLIGHT; k++) {
+            if (!l.gathered_valid[k]) continue;
+            bool hit = k == slot;                                    // the slot about to be reused: its frame must be done
+            for (const void *a : mine) for (const void *b : l.touched[k]) hit = hit || a == b;
+            if (hit) {
+                MG_HIP(m, hipStreamWaitEvent(l.compute, l.gathered[k], 0));
+                if (l.rank == 0) MG_HIP(m, hipStreamWaitEvent(l.gather, l.gathered[k], 0));
+            }
         }
+        l.touched[slot] = mine;
+    }
     for (size_t c = 0; c < n_chunks; c++) {
         // shade chunk c on every local rank
         for (size_t i = 0; i < m->locals.size(); i++) {
@@ -352,8 +373,9 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
     }
     for (Local &l : m->locals) {
         MG_HIP(m, hipSetDevice(l.device));
-        MG_HIP(m, hipEventRecord(l.gathered, l.gather));
-        l.gathered_valid = true;
+        MG_HIP(m, hipEventRecord(l.gathered[l.frame_next], l.gather));
+        l.gathered_valid[l.frame_next] = true;
+        l.frame_next = (l.frame_next + 1) % Local::FRAMES_IN_FLIGHT;
     }
     return MIL_OK;
 }
@@ -384,7 +406,7 @@ void mil_mg_destroy(mil_mg *m)
         (void)hipSetDevice(l.device);
         if (l.comm && rccl().ok) (void)rccl().CommDestroy(l.comm);
         for (hipEvent_t e : l.chunk_done) if (e) (void)hipEventDestroy(e);
-        if (l.gathered) (void)hipEventDestroy(l.gathered);
+        for (hipEvent_t e : l.gathered) if (e) (void)hipEventDestroy(e);
         if (l.compute) (void)hipStreamDestroy(l.compute);
         if (l.gather) (void)hipStreamDestroy(l.gather);
         if (l.ctx) mil_destroy(l.ctx);

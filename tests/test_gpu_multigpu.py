@@ -127,3 +127,39 @@ def test_emulated_ranks_frames_mode():
         assert torch.equal(slots[r], want[r]), r
     mg.close()
     lp.close()
+
+
+def test_frames_in_flight_rotating_and_reused_buffers():
+    """Several frames enqueued without a sync in between: with rotating output buffers (the gather of frame i may run under the
+    shading of frame i + 1) and with ONE buffer reused by every frame (each frame must wait for the previous gather): every
+    assembled frame == the monolithic launch of its own light set, bit for bit.  4 emulated ranks, 16-row bands."""
+    w, h, n = 512, 288, 4
+    cam = synth.sweep_camera(w, h)
+    gb = synth.scene_sweep(w, h, cam, device=DEV)
+    frame = cam.frame_matrix_data()
+    dl = ubo.default_directional_lights()
+    sh = synth.shadow_setup(dl[0, 0:3], 128, device=DEV)
+    lights = [synth.point_light_field(1200, 0x5EED0100 + k) for k in range(6)]
+    lp = lighting.LightingPass(0, 4096)
+    want = [lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_SRGB8) for pl in lights]
+    mg = multigpu.MultiGpu.single_process([0] * n, max_point_lights=4096, band_rows=16, chunks=1, transport=multigpu.TRANSPORT_PEER_COPY)
+    try:
+        rows = [torch.from_numpy(multigpu.frame_rows_of_rank(h, n, r, band_rows=16)).to(DEV) for r in range(n)]
+        parts_gb = [{k: (v[rows[r]].contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()} for r in range(n)]
+        for rotate in (True, False):
+            n_buf = 3 if rotate else 1
+            outs = [[None if r == 0 else torch.zeros((len(rows[r]), w), dtype=torch.int32, device=DEV) for r in range(n)] for _ in range(n_buf)]
+            fulls = [torch.zeros((h, w), dtype=torch.int32, device=DEV) for _ in range(len(lights) if rotate else 1)]
+            for k, pl in enumerate(lights):
+                parts = [dict(gb=parts_gb[r], point_lights=pl, ambient=AMB, shadow=sh, out=outs[k % n_buf][r]) for r in range(n)]
+                mg.render_strips(parts, frame, dl, w, h, fmt=lighting.OUT_SRGB8, full=fulls[k if rotate else 0])
+                if not rotate:          # one destination: look at it before the next frame overwrites it
+                    mg.sync()
+                    assert torch.equal(fulls[0], want[k]), k
+            mg.sync()
+            if rotate:
+                for k in range(len(lights)):
+                    assert torch.equal(fulls[k], want[k]), k
+    finally:
+        mg.close()
+        lp.close()
