@@ -1153,9 +1153,15 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         for (int j = 0; j < 4; j++) __builtin_amdgcn_global_load_lds((gptr_t)(p.rm + i[j]), (lptr_t)(s_tex + (8 + j) * 64), 4, 0, 0);
     }
     const v4f *cull = (const v4f *)p.point_cull;
-    v4f c_first = { 0.0f, 0.0f, 0.0f, 0.0f };
-    if (lane < p.n_point) c_first = cull[lane];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the LDS-DMA writes are ordered only by this wave's vmcnt
+    // The first cull records are requested with the texels - as a cache warm-up only: the culling loop loads them again (an
+    // L1 hit by then).  Kept in registers for the loop instead, they stayed live across the rounds loop and the compiler
+    // parked them in scratch at its entry: 1 KiB written per lit tile's wave, 16.6 MB per headline launch, which is what
+    // WRITE_SIZE showed as a 1.10 x write amplification (147.1 MB against 132.7 MB of hdr) in rounds 1 and 2.
+    {
+        v4f warm = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (lane < p.n_point) warm = cull[lane];
+        asm volatile("s_waitcnt vmcnt(0)" :: "v"(warm) : "memory");   // the LDS-DMA writes are ordered only by this wave's vmcnt
+    }
 
     // ---- 2. AABB of lit pixels + shadow texel rectangle ----
     const float INF = __builtin_inff();
@@ -1243,7 +1249,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             for (; b0 < end && (cnt + 256 <= list_cap || end - b0 <= list_cap - cnt); b0 += 256) {
                 v4f c4[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) c4[u] = (u == 0 && first && b0 == 0) ? c_first : cull[min(b0 + 64 * u + lane, end - 1)];
+                for (int u = 0; u < 4; u++) c4[u] = cull[min(b0 + 64 * u + lane, end - 1)];
 #pragma unroll
                 for (int u = 0; u < 4; u++) {          // straight-line: rejected lanes write the dump entry behind the list
                     const uint32_t li = b0 + 64 * u + lane;
