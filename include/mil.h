@@ -374,7 +374,7 @@ int mil_mg_frame_rows_of_rank(const mil_mg_config *cfg, int world, int rank, uin
 /* What one rank contributes; every pointer on that rank's device. */
 typedef struct mil_mg_rank_io {
     mil_gbuffer gb;               /* the rank's rows of the planes, compacted (gb.height = mil_mg_rows_of_rank; y_offset ignored) */
-    const mil_extras *extras;     /* HOST struct (point lights HOST, shadow map on that device); may be NULL */
+    const mil_extras *extras;     /* HOST struct (point lights HOST, shadow map on that device); may be NULL; ldr_out must be NULL */
     void *out;                    /* the rank's rows of the output, dense (out_pitch_px = width); rank 0 writes straight into the
                                      destination instead (out may be NULL) unless MIL_MG_FLAG_LOOPBACK */
     uint32_t out_pitch_px;

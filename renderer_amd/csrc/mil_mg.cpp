@@ -220,6 +220,7 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
         if (pl.rows == 0) continue;
         const mil_mg_rank_io &r = io[i];
         if (r.gb.height != pl.rows || r.gb.width == 0 || (float)r.gb.width != push->resolution[0]) return MIL_ERR_BAD_ARG;
+        if (r.extras && r.extras->ldr_out) return MIL_ERR_BAD_ARG;      // one gathered image per call: shade to hdr, or to a packed format
         // rank 0 shades straight into its destination unless the loopback test mode routes it through the transport
         in_place[i] = l.rank == 0 && !loopback;
         if (!in_place[i] && (!r.out || r.out_pitch_px != r.gb.width)) return MIL_ERR_BAD_ARG;     // gathered rows travel as dense runs

@@ -82,3 +82,30 @@ def test_ldr_out_needs_the_hdr_format(lp):
         lp.light_ex(gb, frame, dl, None, AMB, None, fmt=lighting.OUT_SRGB8, ldr_out=ldr)
     with pytest.raises(lighting.MilError):
         lp.light_ex(gb, frame, dl, None, AMB, None, ldr_out=torch.zeros((64, 32), dtype=torch.int32, device=DEV))      # pitch < width
+
+
+def test_ldr_out_through_the_entry_point_that_allocates_nothing(lp):
+    gb, frame, dl, pl, sh = scene(200, 120, 150, 64)
+    ref = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    want = lp.tonemap(ref, lighting.OUT_SRGB8)
+    pld = torch.from_numpy(pl).to(DEV)
+    hdr = torch.zeros_like(ref)
+    ldr = torch.zeros_like(want)
+    ex = lighting.Extras()
+    # the mirror's light_ex_noalloc has no ldr_out keyword: the raw call, as a C caller would make it
+    import ctypes
+    import numpy as np
+    from renderer_amd.lighting import _np_ptr
+    lights = np.ascontiguousarray(dl, np.float32).reshape(-1, 8)
+    fr = np.ascontiguousarray(frame, np.float32).reshape(68)
+    push = lp._push(gb, lights.shape[0])
+    ex.point_lights, ex.n_point = pld.data_ptr(), pld.shape[0]
+    ex.ambient = (ctypes.c_float * 3)(*AMB)
+    shs = lighting.Shadow((ctypes.c_float * 16)(*[float(v) for v in sh['light_view_proj']]), sh['map'].data_ptr(), sh['map'].shape[0], float(sh['bias']))
+    ex.shadow = ctypes.pointer(shs)
+    ex.ldr_out, ex.ldr_out_pitch_px = ldr.data_ptr(), ldr.stride(0)
+    g = lp._gb(gb)
+    lp._check(lp.lib.mil_light_ex_noalloc(lp.ctx, ctypes.byref(g), _np_ptr(fr), _np_ptr(lights), _np_ptr(push), ctypes.byref(ex),
+                                          hdr.data_ptr(), hdr.stride(0) // 4, lighting.OUT_HDR, 0, None))
+    torch.cuda.synchronize()
+    assert same(hdr, ref) and torch.equal(ldr, want)
