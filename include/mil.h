@@ -305,7 +305,8 @@ int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
                     const mil_push_constants *push, const mil_point_light *point_lights, uint32_t n_point,
                     unsigned long long *count, void *stream);
 
-/* Tuning.  Fast-mode mil_light_ex launches with at least min_point_lights point lights take the two-kernel form
+/* Tuning.  Fast-mode launches (mil_light_ex, mil_shade_bands, mil_shade_frame; the last with a sky or a resolve subpass
+ * from twice the number) with at least min_point_lights point lights take the two-kernel form
  * (k_bin: classification + two-level culling into per-half-tile lists and cost buckets; k_shade: one wave per listed half
  * tile, most expensive first), the others the one-kernel form (k_tiled); results are bit-identical.  Default
  * MIL_TWO_KERNEL_DEFAULT (measured crossover on a 4K frame); 1 = always, 0xFFFFFFFF = never.  The two-kernel form keeps a

@@ -643,15 +643,21 @@ int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_dat
         p.tile_counts = n_tiles <= c->tile_counts_cap ? c->tile_counts : nullptr;
         p.tile_stamps = n_tiles <= c->tile_stamps_cap ? c->tile_stamps : nullptr;
     }
-    // The two-kernel form (k_bin -> k_shade) serves the fast-mode mil_light_ex launch with point lights; strict mode, the
-    // whole-frame launch, LDS-staged shadows and the wave-stamp diagnostics stay on k_tiled (MIL_TUNE bit 1024 forces it).
+    // The two-kernel form (k_bin -> k_shade) serves the fast-mode launches with many point lights (mil_light_ex, mil_shade_bands
+    // and mil_shade_frame alike); strict mode, LDS-staged shadows and the wave-stamp diagnostics stay on k_tiled (MIL_TUNE bit
+    // 1024 forces it).
     // (MIL_TUNE bit 2048: the stamp buffer, then 8 u32 per tile, goes to k_shade instead: one record per half tile)
     if (tiled && (c->tune & 2048u)) p.tile_stamps = 2u * n_tiles <= c->tile_stamps_cap ? c->tile_stamps : nullptr;
     // Below ~900 point lights k_tiled is the faster of the two on the 4K frame (256 lights: 101 us against 122; 1024: 234
     // against 226; 4096: 625 against 487): the pre-pass costs what culling and sky tiles cost there.  The threshold is a
     // context setting (mil_set_two_kernel_threshold; the parity tests set 1 so that small frames cover both kernels).
-    const bool many = n_point >= c->two_kernel_min;
-    bool two = tiled && many && !strict && !whole && !(flags & MIL_FLAG_NO_CULL) && !p.shadow_lds && (!p.tile_stamps || (c->tune & 2048u)) && !(c->tune & 1024u);
+    // A whole-frame launch with a sky or a resolve subpass makes every half tile an item (k_shade's store does those passes),
+    // which costs the two-kernel form what the sky tiles cost: its break-even is at twice the light count there (4K, measured:
+    // 1536 lights 314 us against 299 for k_tiled, 2048 lights 366 against 378, 4096 lights 526 against 624).
+    const bool frame_items = whole && (p.has_sky || p.accum);
+    const uint64_t two_min = frame_items ? 2ull * c->two_kernel_min : c->two_kernel_min;
+    const bool many = n_point >= two_min;
+    bool two = tiled && many && !strict && !(flags & MIL_FLAG_NO_CULL) && !p.shadow_lds && (!p.tile_stamps || (c->tune & 2048u)) && !(c->tune & 1024u);
     if (two) {
         if (pre)          // the entry point that allocates nothing never grows the workspace
             two = 2u * n_tiles <= c->ws.items_cap && ((n_tiles + MIL_WS_SHARDS - 1u) / MIL_WS_SHARDS) * 2u <= c->ws.seg_cap;
@@ -668,7 +674,7 @@ int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_dat
         HIP_TRY(c, hipMemsetAsync(w.shard_count, 0, (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4 + 256, s));
         le = mil::fast::launch_bin((int)fmt, p, s);
         if (le == hipSuccess) le = mil::fast::launch_order(p, s);
-        if (le == hipSuccess) le = mil::fast::launch_shade((int)fmt, p, s);
+        if (le == hipSuccess) le = mil::fast::launch_shade((int)fmt, p, whole, s);
         if (le == hipSuccess && !pre) {
             HIP_TRY(c, hipEventRecord(w.done, s));
             w.used = true; w.last_stream = s;

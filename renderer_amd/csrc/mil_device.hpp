@@ -1520,10 +1520,17 @@ __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt
 #pragma unroll
     for (int j = 0; j < 4; j++) lit4[j] = xin && (y0 + 4 * j) <= ylast && (u2[j] >> 24) != 0;
     const bool anyA = __builtin_amdgcn_ballot_w64(lit4[0] || lit4[1]) != 0, anyB = __builtin_amdgcn_ballot_w64(lit4[2] || lit4[3]) != 0;
-    // occlusion 0 multiplies every term (fs_deferred_lighting.glsl:63 and the extensions): an unlit half tile is exactly 0
+    // occlusion 0 multiplies every term (fs_deferred_lighting.glsl:63 and the extensions): an unlit half tile is exactly 0.
+    // A whole-frame launch with a sky or a resolve subpass (mil_shade_frame) has more to do for such pixels than a
+    // constant: there every half tile inside the frame becomes an item (empty list, cheapest bucket) and k_shade's store
+    // path (emit_pixel<FMT, true>) does the rest.
+    const bool frame_items = p.has_sky || p.accum != nullptr;
+    const bool itemA = tile_in && (anyA || frame_items), itemB = tile_in && (anyB || (frame_items && tyi * TILE + 8u <= ylast));
+    if (!frame_items) {
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (xin && (y0 + 4 * j) <= ylast && !(j < 2 ? anyA : anyB)) store_zero_rt(fmt, p.out, p.out_pitch, x, y0 + 4 * j + rm.o, p.out2, p.out2_pitch);
+        for (int j = 0; j < 4; j++)
+            if (xin && (y0 + 4 * j) <= ylast && !(j < 2 ? anyA : anyB)) store_zero_rt(fmt, p.out, p.out_pitch, x, y0 + 4 * j + rm.o, p.out2, p.out2_pitch);
+    }
 
     // ---- boxes of the lit pixels of the two half tiles
     const float INF = __builtin_inff();
@@ -1595,10 +1602,10 @@ __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt
 
     // ---- level 2: this wave's two half-tile boxes against the survivors (or against all lights), lists in ascending order
     const uint32_t src_n = coarse ? coarse_n : n_point, stride = p.ws_list_stride;
-    const uint32_t itemA = 2u * (tyi * p.tiles_x + txi);
+    const uint32_t idA = 2u * (tyi * p.tiles_x + txi);
     uint32_t lenA = 0, lenB = 0, cntU = 0;
     if (anyA || anyB) {
-        uint16_t *const listA = p.ws_lists + (size_t)itemA * stride, *const listB = listA + stride;
+        uint16_t *const listA = p.ws_lists + (size_t)idA * stride, *const listB = listA + stride;
 #pragma unroll 1
         for (uint32_t b0 = 0; b0 < src_n; b0 += 256u) {
             uint32_t li4[4];
@@ -1625,20 +1632,20 @@ __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt
         }
     }
     // ---- append the lit half tiles to their cost buckets (one returning add per item on the tile's shard of the counters)
-    if (lane == 0 && tile_in && (anyA || anyB)) {
+    if (lane == 0 && (itemA || itemB)) {
         const uint32_t tile = tyi * p.tiles_x + txi, shard = tile % MIL_WS_SHARDS;
         uint32_t *const seg = p.ws_shard_items + (size_t)shard * MIL_WS_BUCKETS * p.ws_seg_cap;
-        if (anyA) {
+        if (itemA) {
             const bool brute = lenA > stride;             // more lights reach the half tile than a list holds: brute force there
             const uint32_t b = cost_bucket(lenA, brute);
-            p.ws_meta[itemA] = brute ? MIL_WS_BRUTE : lenA;
-            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = itemA;
+            p.ws_meta[idA] = brute ? MIL_WS_BRUTE : lenA;
+            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = idA;
         }
-        if (anyB) {
+        if (itemB) {
             const bool brute = lenB > stride;
             const uint32_t b = cost_bucket(lenB, brute);
-            p.ws_meta[itemA + 1] = brute ? MIL_WS_BRUTE : lenB;
-            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = itemA + 1;
+            p.ws_meta[idA + 1] = brute ? MIL_WS_BRUTE : lenB;
+            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = idA + 1;
         }
     }
     if (lane == 0 && tile_in && p.tile_counts) p.tile_counts[tyi * p.tiles_x + txi] = cntU;
@@ -1674,7 +1681,7 @@ __global__ __launch_bounds__(64) void k_order(const ShadeParams p)
     if (blockIdx.x == 0 && lane == 0) *p.ws_total = ta;
 }
 
-template <int FMT>
+template <int FMT, bool FRAME>
 __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParams p)
 {
     // four independent waves per workgroup, one item each (no barrier, no LDS): single-wave workgroups are admitted to a CU
@@ -1706,6 +1713,11 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
     const RowMap rm = row_map(p, tyi * TILE);
     const bool inA = x < p.width && ya <= ylast, inB = x < p.width && yb <= ylast;
     const bool litA = inA && (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
+    if (FRAME && __builtin_amdgcn_ballot_w64(litA || litB) == 0) {      // a whole-frame item without a lit pixel: sky / resolve of exact zeros
+        if (inA) emit_pixel<FMT, true>(p, x, ya, rm, depth.x, f3{ 0.0f, 0.0f, 0.0f });
+        if (inB) emit_pixel<FMT, true>(p, x, yb, rm, depth.y, f3{ 0.0f, 0.0f, 0.0f });
+        return;
+    }
 
     Px2 q;
     setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth), u1, w2, u3);
@@ -1757,8 +1769,8 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
         r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
         r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
     }
-    if (inA) emit_pixel<FMT, false>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
-    if (inB) emit_pixel<FMT, false>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
+    if (inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
+    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
     if (p.tile_stamps && lane == 0) {                     // diagnostics (MIL_TUNE bit 2048): per ITEM start, end, list length, launch index
         uint32_t *st = p.tile_stamps + 4 * (size_t)item;
         st[0] = (uint32_t)t_start; st[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); st[2] = brute ? 0xFFFFu : len; st[3] = w;
@@ -2241,15 +2253,20 @@ hipError_t launch_order(const ShadeParams &p, hipStream_t s)
 {
     return launch_k(k_order, dim3(MIL_WS_SHARDS * MIL_WS_BUCKETS), dim3(64), 0, s, p);
 }
-hipError_t launch_shade(int fmt, const ShadeParams &p, hipStream_t s)
+hipError_t launch_shade(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {
-    const dim3 grid((2u * p.tiles_x * p.tiles_y + 3u) / 4u), block(256);        // upper bound: every half tile lit
+    const dim3 grid((2u * p.tiles_x * p.tiles_y + 3u) / 4u), block(256);        // upper bound: every half tile listed
+#define MIL_LAUNCH_SHADE(F)                                                   \
+    if (frame) return launch_k(k_shade<F, true>, grid, block, 0, s, p);     \
+    else return launch_k(k_shade<F, false>, grid, block, 0, s, p);
     switch (fmt) {
-    case FMT_HDR: return launch_k(k_shade<FMT_HDR>, grid, block, 0, s, p);
-    case FMT_LDR: return launch_k(k_shade<FMT_LDR>, grid, block, 0, s, p);
-    case FMT_SRGB8: return launch_k(k_shade<FMT_SRGB8>, grid, block, 0, s, p);
-    default: return launch_k(k_shade<FMT_SRGB8_VIA_LDR>, grid, block, 0, s, p);
+    case FMT_HDR: MIL_LAUNCH_SHADE(FMT_HDR); break;
+    case FMT_LDR: MIL_LAUNCH_SHADE(FMT_LDR); break;
+    case FMT_SRGB8: MIL_LAUNCH_SHADE(FMT_SRGB8); break;
+    default: MIL_LAUNCH_SHADE(FMT_SRGB8_VIA_LDR); break;
     }
+#undef MIL_LAUNCH_SHADE
+    return hipErrorInvalidValue;    // not reached: every case returns
 }
 hipError_t launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s)
 {

@@ -129,7 +129,7 @@ hipError_t launch_tonemap(int fmt, const TonemapParams &p, hipStream_t s);
 hipError_t launch_count_pairs(const ShadeParams &p, unsigned long long *count, hipStream_t s);
 hipError_t launch_bin(int fmt, const ShadeParams &p, hipStream_t s);                 // k_bin: classify, cull, bucket (then:)
 hipError_t launch_order(const ShadeParams &p, hipStream_t s);                        // k_order: buckets -> one launch order
-hipError_t launch_shade(int fmt, const ShadeParams &p, hipStream_t s);               // k_shade: one wave per listed half tile
+hipError_t launch_shade(int fmt, const ShadeParams &p, bool frame, hipStream_t s);               // k_shade: one wave per listed half tile
 hipError_t launch_fxaa(const FxaaParams &p, hipStream_t s);
 hipError_t launch_sky(const SkyParams &p, hipStream_t s);
 hipError_t launch_resolve(const ResolveParams &p, hipStream_t s);

@@ -152,3 +152,34 @@ def test_two_kernel_randomised_sweep(two):
     for seed in range(3000, 3040):
         fails += fuzz_parity.one(two, seed)
     assert not fails, fails
+
+
+@pytest.mark.parametrize('w,h,n_point,use_sky,use_acc', [(256, 144, 300, True, True), (250, 141, 90, True, False), (256, 144, 90, False, True),
+                                                         (64, 40, 1500, True, True), (256, 144, 60, False, False)])
+def test_two_kernel_whole_frame(two, one, w, h, n_point, use_sky, use_acc):
+    """mil_shade_frame through k_bin -> k_shade<FMT, FRAME>: with a sky or a resolve subpass every half tile of the frame is an
+    item (the unlit ones with an empty list) and k_shade's store does sky / resolve / tonemap; == the one-kernel form and == the
+    chain of separate calls it folds (tested against that form in test_gpu_parity.py) bit for bit, every format, strips and
+    dealt bands with the passes."""
+    gb, frame, dl, pl, sh = scene('sweep', w, h, n_point, 64)
+    prm = synth.hosek_params_synthetic() if use_sky else None
+    ta, tr = synth.transparency_layer(w, h, DEV) if use_acc else (None, None)
+    for fmt in (lighting.OUT_HDR, lighting.OUT_LDR, lighting.OUT_SRGB8, lighting.OUT_SRGB8_VIA_LDR):
+        a = two.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=fmt)
+        assert same(a, one.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=fmt)), fmt
+    full = two.shade_frame(gb, frame, dl, pl, AMB, sh, sky=prm, accum=ta, reveal=tr, fmt=lighting.OUT_LDR)
+    y0, y1 = 32, 96
+    strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+    strip['y_offset'] = y0
+    part = two.shade_frame(strip, frame, dl, pl, AMB, sh, sky=prm, accum=None if ta is None else ta[y0:y1],
+                           reveal=None if tr is None else tr[y0:y1], fmt=lighting.OUT_LDR)
+    assert same(part, full[y0:y1])
+    if h % 16 == 0:
+        out = torch.zeros_like(full)
+        for r in range(3):
+            rows = torch.from_numpy(lighting.band_rows_of_rank(h, 16, 3, r)).to(DEV)
+            sub = {k: (v[rows].contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()}
+            sub['y_offset'] = 0
+            out[rows] = two.shade_bands(sub, frame, dl, (16, 3, r), pl, AMB, sh, sky=prm, accum=None if ta is None else ta[rows].contiguous(),
+                                        reveal=None if tr is None else tr[rows].contiguous(), fmt=lighting.OUT_LDR)
+        assert same(out, full)
