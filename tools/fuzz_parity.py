@@ -9,7 +9,7 @@ Each iteration draws a frame size, strip, pitch, light counts, shadow size, flag
   * mil_fxaa on a strip                      == the rows of the whole-frame call
   * mil_transparency_accumulate strict       == the C oracle, bit for bit
 FUZZ_BIG=1: frames up to 1000 x 500 with 600 - 4000 point lights and shadow maps up to 2048^2 (seconds per iteration: the C
-oracle is brute force).  Prints one line per failure with the seed that reproduces it; exit status 1 if any."""
+oracle is brute force).  FUZZ_TWO_KERNEL=1: the two-kernel form of the tiled launch at every light count.  Prints one line per failure with the seed that reproduces it; exit status 1 if any."""
 import os
 import sys
 
@@ -147,6 +147,8 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     coracle.build()
     lp = lighting.LightingPass(0, max_point_lights=4096)
+    if os.environ.get('FUZZ_TWO_KERNEL'):       # every culled fast-mode launch through k_bin -> k_shade, whatever the light count
+        lp.set_two_kernel_threshold(1)
     total = []
     for i in range(iters):
         new = one(lp, seed0 + i)
