@@ -91,7 +91,7 @@ typedef uint32_t v2u __attribute__((ext_vector_type(2)));
 template <typename T> struct PxT {
     V3<T> N, V, P;
     T occ;
-    T alpha, a2, am1, NdotV, sV;       // am1 = alpha^2 - 1, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
+    T alpha, a2, oma2, NdotV, sV;      // oma2 = 1 - alpha^2, sV = sqrt((NdotV - a2 NdotV) NdotV + a2)
     V3<T> G0, G1;                      // tint * F0, tint * (f90 - F0), tint = ((1-m) + albedo*m)*occ
     V3<T> dif;                         // albedo/PI*(1-m)*occ
 };
@@ -278,6 +278,21 @@ DEV v2f sat_fnma(v2f a, v2f b, v2f c)      // sat(c - a * b)
     asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\ts_nop 0" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// the same with an inline constant operand (op_sel_hi 0: both halves read the one 32-bit constant): no VGPR pair holds it
+DEV v2f sat_half(v2f a)                    // sat(a / 2)
+{
+    v2f d;
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, 0.5 op_sel_hi:[1,0] clamp\n\ts_nop 0" : "=v"(d) : "v"(a));
+    return d;
+}
+DEV v2f sat_one_minus_mul(v2f a, v2f b)    // sat(1 - a * b)
+{
+    v2f d;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, 1.0 op_sel_hi:[1,1,0] neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\ts_nop 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+DEV float sat_half(float a) { return sat(a * 0.5f); }
+DEV float sat_one_minus_mul(float a, float b) { return sat(__builtin_fmaf(-a, b, 1.0f)); }
 DEV float sat_mul(float a, float b) { return sat(a * b); }
 DEV float sat_fma(float a, float b, float c) { return sat(__builtin_fmaf(a, b, c)); }
 DEV float sat_fnma(float a, float b, float c) { return sat(__builtin_fmaf(-a, b, c)); }
@@ -339,7 +354,7 @@ template <typename T, typename U> DEV void setup_pixel_t(PxT<T> &q, const PosT<T
     q.V = V3<T>{ pos.D.x * rv, pos.D.y * rv, pos.D.z * rv };
     q.alpha = roughness * roughness;
     q.a2 = q.alpha * q.alpha;
-    q.am1 = q.a2 - 1.0f;
+    q.oma2 = 1.0f - q.a2;
     q.NdotV = med3_(dot3(q.N, q.V), 0.0001f, 1.0f);
     q.sV = sqrt_(fma_(fma_(-q.a2, q.NdotV, q.NdotV), q.NdotV, q.a2));
     T om = 1.0f - m;
@@ -358,13 +373,11 @@ DEV void setup_pixel(Px &q, const ShadeParams &, Pos pos, uint32_t u1, uint32_t 
 
 // light() with the invariants in q; rad = lightColor * intensity [* attenuation * shadow].
 //   colour = dif + tint * (F0 + (f90 - F0) w^5) * D * Vis = dif + (G0 + G1 w^5) * DV
-template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T LdotH, V3<T> col, T scale, V3<T> &res)
+template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T s2, T LdotH, V3<T> col, T scale, V3<T> &res)
 {
-    T x2 = NdotH * NdotH;
-    // alpha / ((1-x2) + x2*alpha^2), the denominator rewritten as x2*(alpha^2-1) + 1.  For a mirror-like texel (roughness
-    // byte <= 3) alpha^2 - 1 rounds to -1 and the rewritten form is 0 at N.H = 1 (the literal form gives alpha^2 there):
-    // clamped to that true minimum
-    T t = max_(fma_(x2, q.am1, (T)1.0f), q.a2);
+    // D_GGX's denominator (1 - x^2) + x^2 alpha^2, x = N.H, from s2 = 1 - x^2 (formed without cancellation by the caller,
+    // see one_minus_ndoth2): x^2 = 1 - s2, so t = s2 (1 - alpha^2) + alpha^2 >= alpha^2 > 0
+    T t = fma_(s2, q.oma2, q.a2);
     T sL = sqrt_(fma_(fma_(-q.a2, NdotL, NdotL), NdotL, q.a2));
     T den = fma_(NdotL, q.sV, q.NdotV * sL);                             // GGXV + GGXL
     // D * Vis = (alpha / t)^2 * 0.5 / (pi den) with ONE reciprocal (a quarter-rate instruction: 16 cycles a wave against 4):
@@ -382,13 +395,30 @@ template <typename T> DEV void eval_tail(const PxT<T> &q, T NdotL, T NdotH, T Ld
     res.z = fma_(cz, col.z * sN, res.z);
 }
 // general L (directional lights are not normalised by the shader, inc_structs.glsl:12-16)
+// 1 - clamp(N.H, 0, 1)^2 for the D_GGX denominator (inc_brdf.glsl:3-5).  Formed as 1 - x * x from a rounded x it carries
+// an ABSOLUTE error of ~1e-7 whatever its size, while the denominator goes down to alpha^2 (2e-8 for the roughness-0.01
+// spheres of scenes/roughness_test.rs): round 2's census had 532 pixels of the 4K headline frame outside
+// 1e-3 + 1e-4 |b| of the float64 result, all of them on such highlights, 129 of them where even the reference-order FP32
+// result is inside.  For unit vectors |N - Hn|^2 = 2 - 2 N.Hn =: e, so 1 - x = e / 2 and 1 - x^2 = (e/2)(2 - e/2): the
+// difference N - Hn is taken component by component with one rounding (fma), its error is RELATIVE to the angle between
+// the two, and a length error eps of N or Hn only adds eps^2.  N.H <= 0 (x clamped to 0, s2 = 1) is e >= 2: the
+// saturate of e / 2 does it.  Census with this form: 4-10 pixels outside the bare bar, own 0-1 (tools/fast_emul.py).
+template <typename T> DEV T one_minus_ndoth2(const V3<T> &N, const V3<T> &H, T rh)
+{
+    const V3<T> d = { fma_(-H.x, rh, N.x), fma_(-H.y, rh, N.y), fma_(-H.z, rh, N.z) };
+    const T h = sat_half(dot3(d, d));
+    return h * (2.0f - h);
+}
+// general L (directional lights are not normalised by the shader, inc_structs.glsl:12-16)
 template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
     V3<T> H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
     // L = -V (light straight behind the pixel as seen from the camera): H = 0 and normalize(H) is NaN in the literal
-    // shader; here |H|^2 is floored, N.H and L.H come out 0 and the term dies with N.L = 0 as it should
+    // shader; here |H|^2 is floored, Hn and L.H come out 0 and every factor stays finite
     T rh = rsq_(max_(dot3(H, H), (T)(1e-30f)));
-    eval_tail<T>(q, sat_fma(q.N.z, L.z, fma_(q.N.y, L.y, q.N.x * L.x)), sat_mul(dot3(q.N, H), rh), sat_mul(dot3(L, H), rh), col, scale, res);
+    const T LdotH = sat_mul(dot3(L, H), rh);
+    const T s2 = one_minus_ndoth2<T>(q.N, H, rh);
+    eval_tail<T>(q, sat_fma(q.N.z, L.z, fma_(q.N.y, L.y, q.N.x * L.x)), s2, LdotH, col, scale, res);
 }
 // Point lights (L normalised here) take the same literal H = L + V.  The unit-length shortcut |L+V|^2 = 2 + 2 L.V,
 // N.H = (N.L + N.V) / |L+V| is six packed instructions per pair shorter (-5 % on the headline frame) but cancels when the
@@ -474,7 +504,7 @@ DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1
 {
     v2f inv = rsq_(d2 + 1e-12f);
     V3<v2f> L = { Lv.x * inv, Lv.y * inv, Lv.z * inv };
-    v2f qq = d2 * b.w, w = sat_fnma(qq, qq, (v2f)(1.0f));
+    v2f qq = d2 * b.w, w = sat_one_minus_mul(qq, qq);
     v2f att = (w * w) * rcp_(d2 + 1e-4f);
     att = v2f{ on0 ? att.x : 0.0f, on1 ? att.y : 0.0f };          // see point_eval
     eval_light_unit<v2f>(q, L, V3<v2f>{ (v2f)(b.x), (v2f)(b.y), (v2f)(b.z) }, att, res);
@@ -2103,7 +2133,7 @@ __global__ __launch_bounds__(256) void k_accumulate(const AccumParams p)
     const f3 n = { no.x, no.y, no.z }, D = { p.cam[0] - pz.x, p.cam[1] - pz.y, p.cam[2] - pz.z };
     const float rn = rsq_(dot3(n, n)), rv = rsq_(dot3(D, D));
     const f3 N = { n.x * rn, n.y * rn, n.z * rn }, V = { D.x * rv, D.y * rv, D.z * rv };
-    const float a2 = alpha * alpha, am1 = a2 - 1.0f;
+    const float a2 = alpha * alpha, oma2 = 1.0f - a2;
     const float NdotV = med3_(dot3(N, V), 0.0001f, 1.0f);
     const float sV = sqrt_(fma_(fma_(-a2, NdotV, NdotV), NdotV, a2));
     const float om = 1.0f - metallic;
@@ -2114,9 +2144,8 @@ __global__ __launch_bounds__(256) void k_accumulate(const AccumParams p)
         const DirRec d = accum_dir_rec(p, l);
         const f3 L = { d.a.x, d.a.y, d.a.z }, H = { L.x + V.x, L.y + V.y, L.z + V.z };
         const float rh = rsq_(max_(dot3(H, H), 1e-30f));                              // L = -V: see eval_light
-        const float NdotL = sat(dot3(N, L)), NdotH = sat(dot3(N, H) * rh), LdotH = sat(dot3(L, H) * rh);
-        const float x2 = NdotH * NdotH;
-        const float k = alpha * rcp_(max_(fma_(x2, am1, 1.0f), a2));                   // see eval_tail
+        const float NdotL = sat(dot3(N, L)), LdotH = sat(dot3(L, H) * rh);
+        const float k = alpha * rcp_(fma_(one_minus_ndoth2<float>(N, H, rh), oma2, a2));   // see eval_tail; alpha = 0 at N.H = 1 is 0 / 0 as in the shader (:104 does not clamp)
         const float sL = sqrt_(fma_(fma_(-a2, NdotL, NdotL), NdotL, a2));
         const float den = fma_(NdotL, sV, NdotV * sL);
         const float t = ((k * k) * ((0.5f / PI_LIT) * rcp_(den))) * NdotL;            // D * Vis * NdotL

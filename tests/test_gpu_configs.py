@@ -78,7 +78,7 @@ def test_cfg1_720p_one_directional_plus_ambient(lp, coracle):
     print(f'cfg1: of {w * h} pixels {int(bare.sum())} are outside the bare 1e-3 + 1e-4|b| (mirror highlights of the roughness-0.01 '
           f'spheres, HDR values up to {r64[..., :3].max():.3g}; max abs err {emax:.3g}); {int(own.sum())} of them where the reference-order '
           f'FP32 evaluation is inside it; {int(with_cond.sum())} outside bar + conditioning term')
-    assert with_cond.sum() == 0 and bare.sum() <= 64 and own.sum() <= 8
+    assert with_cond.sum() == 0 and bare.sum() <= 8 and own.sum() <= 2               # measured: 0 / 0
     assert np.all(fast[..., 3] == 1.0)
     # the ambient term is there: the same frame without it is darker wherever albedo * occlusion > 0
     no_amb = lp.light_ex(gb, frame, dl, None, None, None).cpu().numpy()
@@ -178,9 +178,10 @@ def test_headline_4k_bare_tolerance_census(lp, coracle):
     bare, with_cond, own, emax, ref8 = census(None, fast)
     print(f'headline 4K, no shadow: of {w * h} pixels {int(bare.sum())} are outside the bare 1e-3 + 1e-4|b|, {int(own.sum())} of them where the '
           f'reference-order FP32 evaluation is inside it, {int(with_cond.sum())} outside bar + conditioning term (max abs err {emax:.3g})')
-    # measured on MI355X (round 2): 532 / 129 / 0 of 8 294 400 - the conditioning term carries 6.4e-5 of the frame, all of it
-    # GGX highlights of the mirror-like spheres and hot spots next to a point light (values up to 1e5)
-    assert with_cond.sum() == 0 and bare.sum() <= 1100 and own.sum() <= 300
+    # round 2 measured 532 / 129 / 0 of 8 294 400 here, all of it GGX highlights of the mirror-like spheres: 1 - (N.H)^2 formed
+    # from a rounded N.H.  Since round 3 the fast path forms it as |N - H|^2 (one_minus_ndoth2, csrc/mil_device.hpp) and is
+    # closer to float64 there than the reference-order FP32 evaluation is: north_star's bare bar is the ceiling again
+    assert with_cond.sum() == 0 and bare.sum() <= 32 and own.sum() <= 4            # measured: 3 / 0 / 0 (VERDICT r2 asked for 256 / 16)
     got8 = channels(lp.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8).cpu().numpy().view(np.uint32))
     d8 = np.abs(got8 - ref8).max(-1)
     r64 = coracle.shade_f64(*planes, frame, dl, point_lights=pl, ambient=AMB)
@@ -188,7 +189,7 @@ def test_headline_4k_bare_tolerance_census(lp, coracle):
     for (y, x) in np.argwhere(d8 > 1)[:8]:
         print(f'  > 1 LSB at ({x}, {y}): sRGB8 {got8[y, x]} vs {ref8[y, x]}; hdr fast {fast[y, x, :3]}, FP32 reference order {ref32[y, x, :3]}, f64 {r64[y, x, :3]}')
     print(f'headline 4K, no shadow: {int((d8 > 1).sum())} pixels differ by more than 1 LSB after tonemap + sRGB8, {int((d8 > 0).sum())} by 1 LSB')
-    assert (d8 > 1).sum() <= 8                                             # <= 1 LSB after 8-bit tonemap
+    assert (d8 > 1).sum() == 0                                             # <= 1 LSB after 8-bit tonemap, every pixel
     fast = lp.light_ex(gb, frame, dl, pl, AMB, sh).cpu().numpy()
     bare_s, with_cond_s, own_s, emax, ref8 = census(sh, fast)
     print(f'headline 4K, PCF 2048^2: {int(bare_s.sum())} pixels outside the bare bar (PCF taps sitting on the bias flip a ninth of light 0), '

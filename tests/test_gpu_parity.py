@@ -5,10 +5,11 @@ Bars:
   * strict mode (MIL_FLAG_STRICT): BIT-EXACT against oracle/mil_oracle.c (FP32, GLSL
     operator order) for HDR, R11G11B10F and the LUT-based sRGB8 path;
   * fast mode (default): |a-b| <= 1e-3 + 1e-4*|b| in linear HDR against the float64
-    oracle (BASELINE.md / north_star), widened only by the conditioning term
-    8*2^-24*cond where the reference's own D_GGX is ill-conditioned in FP32, and <= 1 LSB
-    after tonemap + sRGB8; PCF is a discrete test, so with shadows on at most 0.1 % of the
-    pixels may differ by one tap;
+    oracle (BASELINE.md / north_star), bare, every pixel of every fixed test (round 3: the
+    fast path forms D_GGX's 1 - (N.H)^2 without cancellation; the conditioning term
+    8*2^-24*cond of rounds 1-2 remains only in the seeded fuzz, whose frames put a light ON a
+    pixel), and <= 1 LSB after tonemap + sRGB8; PCF is a discrete test, so with shadows on at
+    most 0.1 % of the pixels may differ by one tap;
   * integer / index work (culling, strips, fused-vs-unfused) bit-exact in both modes.
 """
 import ctypes
@@ -66,9 +67,11 @@ def assert_bits_equal(a, b, what=''):
 
 def fast_tolerance_ok(gpu, planes, frame, dl, pl=None, amb=None, sh=None, y_offset=0, full_height=None,
                       max_bad_frac=0.0):
-    ref, cond = mo.shade(*planes, frame, dl, point_lights=pl, ambient=amb, shadow=sh, want_cond=True,
-                         y_offset=y_offset, full_height=full_height)
-    tol = 1e-3 + 1e-4 * np.abs(ref[..., :3]) + 8 * 2.0 ** -24 * cond
+    """north_star's bar, bare: |a - b| <= 1e-3 + 1e-4 |b| per channel against the float64 oracle, every pixel (max_bad_frac
+    > 0 only where a PCF tap may sit on the bias).  Rounds 1-2 added a conditioning term 8 x 2^-24 x cond for D_GGX at
+    mirror alignment; since the fast path forms 1 - (N.H)^2 without cancellation (one_minus_ndoth2) no fixed test needs it."""
+    ref = mo.shade(*planes, frame, dl, point_lights=pl, ambient=amb, shadow=sh, y_offset=y_offset, full_height=full_height)
+    tol = 1e-3 + 1e-4 * np.abs(ref[..., :3])
     err = np.abs(gpu[..., :3].astype(np.float64) - ref[..., :3])
     bad = (err > tol) | ~np.isfinite(gpu[..., :3])
     frac = bad.any(-1).mean()
@@ -235,9 +238,14 @@ def test_golden_fixtures_on_gpu(lp):
         assert_bits_equal(hdr.cpu().numpy(), z['hdr_c32'], name)
         np.testing.assert_array_equal(lp.tonemap(hdr, lighting.OUT_LDR, strict=True).cpu().numpy().view(np.uint32), z['ldr_c32'])
         np.testing.assert_array_equal(lp.tonemap(hdr, lighting.OUT_SRGB8_VIA_LDR, strict=True).cpu().numpy().view(np.uint32), z['srgb8_via_ldr_c32'])
+        # fast mode: the bar of every other fast-mode test (fast_tolerance_ok), PCF taps on the bias aside
+        planes = tuple(np.ascontiguousarray(z[k]) for k in ('normal', 'albedo_occ', 'rough_metal', 'depth'))
+        shn = dict(light_view_proj=z['shadow_lvp'], map=z['shadow_map'], bias=float(z['shadow_bias']))
+        fast = lp.light_ex(gb, z['frame'], z['dir_lights'], z['point_lights'], z['ambient'], None).cpu().numpy()
+        fast_tolerance_ok(fast, planes, z['frame'], z['dir_lights'], z['point_lights'], z['ambient'], None)
         fast = lp.light_ex(gb, z['frame'], z['dir_lights'], z['point_lights'], z['ambient'], sh).cpu().numpy()
-        tol = 1e-3 + 1e-4 * np.abs(z['hdr_f64']) + 1e-3 * np.abs(z['hdr_f64']) * (name.startswith('noise'))
-        assert (np.abs(fast - z['hdr_f64']) > tol).any(-1).mean() < 5e-3
+        ref = fast_tolerance_ok(fast, planes, z['frame'], z['dir_lights'], z['point_lights'], z['ambient'], shn, max_bad_frac=1e-3)
+        np.testing.assert_allclose(ref, z['hdr_f64'], rtol=1e-9, atol=1e-12)      # the committed float64 image is what the oracle makes today
 
 
 @pytest.mark.parametrize('kind,w,h', [('sweep', 320, 180), ('noise', 128, 72)])
@@ -396,10 +404,17 @@ def test_fuzz_random_frames_and_degenerate_lights(lp, coracle):
         a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
         b = lp.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL)
         assert torch.equal(a.view(torch.int32), b.view(torch.int32)), f'fuzz {it}: culled != brute force'
-        fin = np.isfinite(ref[..., :3]).all(-1)
+        # fast mode against the float64 oracle: the bare bar + the conditioning term (the light sitting on a pixel is a hot
+        # spot 1 / (d^2 + 1e-4) that amplifies the FP32 rounding of the reconstructed position; noise frames hold
+        # roughness byte 0, alpha = 1e-8); a PCF tap on the bias may flip a pixel or two
+        r64, cond = coracle.shade_f64(*planes, frame, dl, point_lights=pl, ambient=AMB, shadow=sh_np(sh), want_cond=True)
+        fin = np.isfinite(r64[..., :3]).all(-1)
         fa = a.cpu().numpy()
-        tol = 2e-3 + 2e-3 * np.abs(ref[..., :3])         # loose: noise frames contain the ill-conditioned mirror cases
-        assert ((np.abs(fa[..., :3] - ref[..., :3]) > tol).any(-1) & fin).mean() < 0.02
+        err = np.abs(fa[..., :3] - r64[..., :3])
+        bare = ((err > 1e-3 + 1e-4 * np.abs(r64[..., :3])).any(-1) & fin).sum()
+        bad = ((err > 1e-3 + 1e-4 * np.abs(r64[..., :3]) + 8 * 2.0 ** -24 * cond).any(-1) & fin).sum()
+        print(f'fuzz {it} ({w}x{h}, {n} lights): {int(bare)} pixels outside the bare bar, {int(bad)} outside bar + conditioning term')
+        assert bad <= max(2, 2e-3 * w * h), (it, int(bad))
 
 
 # ------------------------------------------------------------------ next row f-1: FXAA
@@ -521,9 +536,9 @@ def test_transparency_accumulate(lp, coracle):
         fa, frv = lp.transparency_accumulate(dev, frame, dl)
         ra, rr, cond = mo.transparency_accumulate(*args, want_cond=True)
         assert np.isfinite(ra).all()
-        tol = 1e-3 + 1e-4 * np.abs(ra) + 8 * 2.0 ** -24 * cond          # as shade_and_compare: D_GGX ill-conditioned at mirror alignment
-        assert np.all(np.abs(fa.cpu().numpy() - ra) <= tol), (n, n_dir, float((np.abs(fa.cpu().numpy() - ra) / tol).max()))
-        assert np.all(np.abs(ca - ra) <= tol)
+        bare = 1e-3 + 1e-4 * np.abs(ra)                                  # north_star's bar, bare, for the fast kernel
+        assert np.all(np.abs(fa.cpu().numpy() - ra) <= bare), (n, n_dir, float((np.abs(fa.cpu().numpy() - ra) / bare).max()))
+        assert np.all(np.abs(ca - ra) <= bare + 8 * 2.0 ** -24 * cond)  # the reference-order FP32 evaluation needs the D_GGX conditioning term
         assert np.array_equal(frv.cpu().numpy(), fr['normal_opacity'][:, 3])
     # the lighting call of the frame and the accumulate call share the staged light slot (same lights UBO in the reference)
     gb, frame2, dl2, pl, _ = make_scene('sweep', 96, 64, n_point=16)

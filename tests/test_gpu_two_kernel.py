@@ -134,10 +134,10 @@ def test_two_kernel_fast_tolerance_and_noalloc(two, coracle):
     gb, frame, dl, pl, sh = scene('sweep', 320, 180, 200, 0)
     g = synth.to_numpy(gb)
     planes = (g['normal'], g['albedo_occ'], g['rough_metal'], g['depth'])
-    r64, cond = coracle.shade_f64(*planes, frame, dl, point_lights=pl, ambient=AMB, want_cond=True)
+    r64 = coracle.shade_f64(*planes, frame, dl, point_lights=pl, ambient=AMB)
     fast = two.light_ex(gb, frame, dl, pl, AMB, None).cpu().numpy()
     err = np.abs(fast[..., :3] - r64[..., :3])
-    assert np.all(err <= 1e-3 + 1e-4 * np.abs(r64[..., :3]) + 8 * 2.0 ** -24 * cond) and np.all(fast[..., 3] == 1.0)
+    assert np.all(err <= 1e-3 + 1e-4 * np.abs(r64[..., :3])) and np.all(fast[..., 3] == 1.0)      # north_star's bar, bare
     # the entry point that allocates nothing takes the two kernels too (its workspace was reserved at mil_create)
     a = two.light_ex_noalloc(gb, frame, dl, torch.from_numpy(pl).to(DEV), AMB, None)
     assert same(a, two.light_ex(gb, frame, dl, pl, AMB, None))
