@@ -534,8 +534,38 @@ def emit(res, saved_stdout):
     os.dup2(2, 1)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks as CHILD processes of this one - which has made no
+    GPU call and imports nothing that does - with the driver's own command line, relay rank 0's one JSON line, return the
+    launcher's exit code.  No exec: the parent stays and only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as so:          # a free rendezvous port on the loopback address
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f'bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks as child processes: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), MIL_BENCH_CHILD='1')
+    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in child.stdout.decode(errors='replace').splitlines():
+        try:
+            if 'metric' in json.loads(ln):
+                line = ln
+        except ValueError:
+            print(ln, file=sys.stderr)          # anything else a rank wrote to stdout
+    if child.returncode == 0 and line is not None:
+        print(line, flush=True)
+        return 0
+    print(f'bench.py: the {args.gpus}-rank run failed (launcher exit code {child.returncode}' + ('' if line else ', no result line') + ')', file=sys.stderr)
+    return child.returncode or 1
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
     # stdout carries exactly one JSON line: everything else that lands on file descriptor 1 while the bench runs (RCCL prints a
     # version banner there when a communicator is created, inside torch as well as inside libmil) goes to stderr
     sys.stdout.flush()
@@ -548,10 +578,11 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit('for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N '
-                     '--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...')
         args.gpus = world
+    n_dev = torch.cuda.device_count()       # counting devices does not initialise the GPU
+    rehearse_env = os.environ.get('MIL_BENCH_REHEARSE') == '1'
+    if n_dev == 0 or (local_rank >= n_dev and not rehearse_env):
+        sys.exit(f'bench.py rank {rank}: MIL_ERR_NO_DEVICE (-4): local rank {local_rank} has no GPU ({n_dev} visible); there is no CPU path')
     dist = None
     # rehearsal on a one-GPU box only: MIL_BENCH_REHEARSE=1 puts every rank on device 0 and joins them over gloo
     # (RCCL refuses two ranks on one device); the numbers of such a run mean nothing

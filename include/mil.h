@@ -229,10 +229,21 @@ int mil_light_ex(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_dat
  *     HBM; the prepared records the kernels read are derived by a small kernel on `stream`;
  *   - n_point <= MIL_NOALLOC_MAX_POINT_LIGHTS, else MIL_ERR_CAPACITY (the context's own capacity does not apply);
  *   - the staging buffer is a static __device__ array of the library (334 080 bytes per GPU, held until the process
- *     ends) instead of the context's ring: the call enqueues at most two kernels on `stream` and calls no hipMalloc /
- *     hipFree / hipMemcpy / event or stream routine.  Every call on one GPU shares that array: calls that OVERLAP on one
- *     GPU (two streams, two threads, two contexts) race - serialise them.  The K2 launch order is the plain one (the
- *     host never sees the lights); speed only. */
+ *     ends) instead of the context's ring.  The call makes no hipMalloc / hipFree / hipMemcpy and creates nothing.  It
+ *     enqueues on `stream`: k_prepare_lights (when there are point lights or more than 4 directional ones), then ONE
+ *     shading kernel (k_stream2 / k_tiled), or from the context's two-kernel threshold on (1024 point lights) a
+ *     hipMemsetAsync of 8.4 KB of workspace counters + k_bin + k_order + k_shade.  Every call on one GPU shares that
+ *     array: calls that OVERLAP on one GPU (two streams, two threads, two contexts) race - serialise them.  The K2 launch
+ *     order is the plain one (the host never sees the lights); speed only;
+ *   - the two-kernel form uses the context's workspace, which this entry point never grows (a frame beyond the reserved
+ *     size - mil_create: 7680 x 4320, mil_reserve raises it - takes k_tiled).  Outside stream capture the call joins the
+ *     context's cross-stream protocol like mil_light_ex (hipStreamWaitEvent / hipEventRecord on the workspace's event:
+ *     neither allocates), so it may alternate with other shading calls of the same context on other streams.  UNDER
+ *     CAPTURE (hipStreamBeginCapture on `stream`) no outside event may be touched: the captured launch is outside that
+ *     protocol - ordering replays of the graph against other shading calls of the same context is the caller's - and the
+ *     workspace is pinned from then on (the graph holds its addresses): it is never freed or moved again, later frames
+ *     that would need a larger one take k_tiled, and mil_reserve / mil_set_list_pool return MIL_ERR_CAPACITY when they
+ *     would have to move it. */
 #define MIL_NOALLOC_MAX_POINT_LIGHTS 4096u
 int mil_light_ex_noalloc(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
                          const mil_directional_light *lights, const mil_push_constants *push,
@@ -307,14 +318,38 @@ int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
 
 /* Tuning.  Fast-mode launches (mil_light_ex, mil_shade_bands, mil_shade_frame; the last with a sky or a resolve subpass
  * from twice the number) with at least min_point_lights point lights take the two-kernel form
- * (k_bin: classification + two-level culling into per-half-tile lists and cost buckets; k_shade: one wave per listed half
- * tile, most expensive first), the others the one-kernel form (k_tiled); results are bit-identical.  Default
- * MIL_TWO_KERNEL_DEFAULT (measured crossover on a 4K frame); 1 = always, 0xFFFFFFFF = never.  The two-kernel form keeps a
- * workspace sized for the largest frame shaded so far: like the reference, which recreates its attachments on resize
- * (render/pbr/mod.rs:263-346), a LARGER frame reallocates it (hipFree + hipMalloc: waits for the device); mil_create
- * reserves a 3840 x 2160 frame.  One workspace per context: launches of one context on different streams are serialised. */
+ * (k_bin: classification + two-level culling into compact per-half-tile lists; k_order: counting sort by list length;
+ * k_shade: one wave per listed half tile, most expensive first), the others the one-kernel form (k_tiled); results are
+ * bit-identical.  Default MIL_TWO_KERNEL_DEFAULT (measured crossover on a 4K frame); 1 = always, 0xFFFFFFFF = never.
+ * One workspace per context: launches of one context on different streams are serialised. */
 #define MIL_TWO_KERNEL_DEFAULT 1024u
 int mil_set_two_kernel_threshold(mil_ctx *ctx, uint32_t min_point_lights);
+
+/* The two-kernel form's workspace.  NO COUNTERPART IN THE REFERENCE beyond this: its attachments are allocated when the
+ * window is created and recreated on a resize (render/pbr/mod.rs:98-261, 263-346), never inside Frame::build; likewise no
+ * per-frame entry point of this library allocates for frames up to the reserved size.  mil_create (max_point_lights > 0)
+ * reserves 16 bytes per half tile of a 7680 x 4320 frame + a POOL of 2048 light-list entries (2 bytes) per point light of
+ * the capacity, clamped to 1 Mi .. 8 Mi entries: 20.9 MB for 4096 lights (the 8K / 4096-light frame of BASELINE.json uses
+ * ~7 M entries, the 4K one ~2 M).
+ *   mil_reserve        make per-frame calls on frames up to width x height allocation-free (call it where the reference
+ *                      recreates its attachments); a larger frame still works: the call grows the workspace once
+ *                      (hipFree + hipMalloc: waits for the device; counted in frame_call_allocations).
+ *   mil_set_list_pool  resize the pool (entries).  A pool too small for a frame costs speed, never correctness: the 64x64
+ *                      macro tiles whose lists found no room are shaded by the brute-force loop (same bits).
+ *   mil_workspace_info what is reserved and what the last two-kernel launch used (waits for that launch). */
+typedef struct mil_workspace_stats {
+    uint64_t bytes;                  /* device bytes of the workspace */
+    uint32_t half_tiles;             /* half tiles (16x8) it holds: 2 * ceil(w/16) * ceil(h/16) of the reserved frame */
+    uint32_t pool_entries;           /* list entries the pool holds */
+    uint32_t list_entries_max;       /* longest list kept (<= 960); a half tile more lights reach is shaded by brute force */
+    uint32_t last_items;             /* half tiles the last two-kernel launch listed */
+    uint32_t last_pool_entries;      /* list entries it asked for */
+    uint32_t last_brute_macro_tiles; /* 64x64 macro tiles whose lists found no room in the pool (shaded by brute force) */
+    uint32_t frame_call_allocations; /* times a per-frame call had to grow the workspace since mil_create */
+} mil_workspace_stats;
+int mil_reserve(mil_ctx *ctx, uint32_t width, uint32_t height);
+int mil_set_list_pool(mil_ctx *ctx, uint32_t entries);
+int mil_workspace_info(mil_ctx *ctx, mil_workspace_stats *out);
 
 /* After a culled mil_light_ex: per-tile light-list lengths of that call are written to
  * `counts` (DEVICE, n_tiles uint32) when set before the call; NULL disables.  A launch with more than n_tiles
@@ -387,8 +422,10 @@ typedef struct mil_mg_rank_io {
  * The call returns when the work is enqueued (mil_mg_sync waits).  Calls may follow one another without a sync: a frame
  * waits for the transfers of an earlier frame only when it writes a buffer (io[].out, full, a slot) that frame used, so a
  * caller that rotates its buffers has the gather of frame i running under the shading of frame i + 1; up to four frames are
- * tracked.  Dealt bands are received into a staging area the handle allocates on rank 0's device when the first frame (or a
- * larger one) is rendered - the only allocation of a per-frame call - and scattered into `full` from there. */
+ * tracked.  Dealt bands are received into a staging area on rank 0's device and scattered into `full` from there:
+ * mil_mg_reserve allocates it (and every local context's workspace, mil_reserve) for a frame size AHEAD of the frame loop,
+ * so that no per-frame call allocates; without it the first frame (or a larger one) allocates it inside the call. */
+int mil_mg_reserve(mil_mg *mg, uint32_t width, uint32_t height, mil_out_format fmt);
 int mil_mg_render_strips(mil_mg *mg, const mil_mg_rank_io *io, const mil_frame_matrix_data *frame,
                          const mil_directional_light *lights, const mil_push_constants *push, mil_out_format fmt,
                          uint32_t flags, void *full, uint32_t full_pitch_px);

@@ -351,31 +351,43 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     slot.valid = true;
 }
 
-// Make the workspace hold `items` half tiles (TileWorkspace, mil_internal.h).  Grows only; growing waits for the device.
-int workspace_reserve(mil_ctx *c, uint32_t tiles_x, uint32_t tiles_y)
+// Make the workspace hold `items` half tiles and a pool of `pool` list entries (TileWorkspace, mil_internal.h).  Grows only;
+// growing frees the old one (which waits for the kernels that use it) and allocates.
+int workspace_reserve(mil_ctx *c, uint32_t items, uint32_t pool, bool in_frame_call)
 {
     TileWorkspace &w = c->ws;
-    const uint32_t items = 2u * tiles_x * tiles_y;
-    // a shard's segment holds the half tiles of its tiles: every MIL_WS_SHARDS-th tile, two each
-    const uint32_t seg = ((tiles_x * tiles_y + MIL_WS_SHARDS - 1u) / MIL_WS_SHARDS) * 2u;
-    if (items <= w.items_cap && seg <= w.seg_cap) return MIL_OK;
-    if (w.base) { HIP_TRY(c, hipFree(w.base)); w.base = nullptr; w.items_cap = 0; w.seg_cap = 0; }      // hipFree waits for the kernels that use it
-    const uint32_t stride = c->max_point < MIL_WS_LIST_MAX ? ((c->max_point + 63u) & ~63u) : MIL_WS_LIST_MAX;
-    const size_t counts_b = (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4 + 256;
-    const size_t items_b = ((size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * seg * 4 + 255) & ~(size_t)255;
-    const size_t order_b = ((size_t)items * 4 + 255) & ~(size_t)255, meta_b = order_b;
-    const size_t lists_b = (size_t)items * (stride ? stride : 64u) * 2;
-    HIP_TRY(c, hipMalloc((void **)&w.base, counts_b + items_b + order_b + meta_b + lists_b));
-    w.shard_count = (uint32_t *)w.base;
-    w.total = (uint32_t *)(w.base + (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4);
-    w.shard_items = (uint32_t *)(w.base + counts_b);
-    w.order = (uint32_t *)(w.base + counts_b + items_b);
-    w.meta = (uint32_t *)(w.base + counts_b + items_b + order_b);
-    w.lists = (uint16_t *)(w.base + counts_b + items_b + order_b + meta_b);
-    w.items_cap = items; w.list_stride_max = stride ? stride : 64u; w.seg_cap = seg;
+    if (items <= w.items_cap && pool <= w.pool_cap) return MIL_OK;
+    if (w.pinned) return MIL_ERR_CAPACITY;          // a captured graph may hold the pointers (mil_light_ex_noalloc)
+    items = items > w.items_cap ? items : w.items_cap;
+    pool = pool > w.pool_cap ? pool : w.pool_cap;
+    if (w.base) { HIP_TRY(c, hipFree(w.base)); w.base = nullptr; w.items_cap = 0; w.pool_cap = 0; }
+    const size_t order_b = ((size_t)items * 4 + 255) & ~(size_t)255, meta_b = ((size_t)items * 8 + 255) & ~(size_t)255;
+    const size_t pool_b = ((size_t)pool * 2 + 255) & ~(size_t)255;
+    w.bytes = WS_COUNTER_BYTES + 2 * order_b + meta_b + pool_b;
+    HIP_TRY(c, hipMalloc((void **)&w.base, w.bytes));
+    w.hist = (uint32_t *)w.base;
+    w.total = w.hist + MIL_WS_BUCKETS * MIL_WS_SHARDS;
+    w.pool_used = w.total + 32;          // the next 128-byte line
+    w.order = (uint32_t *)(w.base + WS_COUNTER_BYTES);
+    w.rank = (uint32_t *)(w.base + WS_COUNTER_BYTES + order_b);
+    w.meta = (uint2 *)(w.base + WS_COUNTER_BYTES + 2 * order_b);
+    w.pool = (uint16_t *)(w.base + WS_COUNTER_BYTES + 2 * order_b + meta_b);
+    w.items_cap = items; w.pool_cap = pool;
+    w.list_cap = c->max_point < MIL_WS_LIST_MAX ? ((c->max_point + 63u) & ~63u) : MIL_WS_LIST_MAX;
+    if (w.list_cap == 0) w.list_cap = 64u;
     w.used = false;
+    if (in_frame_call) w.frame_call_allocs++;
     if (!w.done) HIP_TRY(c, hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
     return MIL_OK;
+}
+uint32_t items_of(uint32_t width, uint32_t height)
+{
+    return 2u * ((width + MIL_TILE - 1) / MIL_TILE) * ((height + MIL_TILE - 1) / MIL_TILE);
+}
+uint32_t default_pool(uint32_t max_point)
+{
+    const uint64_t e = 2048ull * max_point;
+    return (uint32_t)(e < (1u << 20) ? (1u << 20) : (e > (8u << 20) ? (8u << 20) : e));
 }
 
 // A launch was issued (status `launch`); remember on which stream the slot's content is being read.
@@ -456,7 +468,7 @@ int mil_create(mil_ctx **out, int device, uint32_t max_point_lights)
             if (hipEventCreateWithFlags(&s.done[k], hipEventDisableTiming) != hipSuccess) rc = MIL_ERR_HIP;
     }
     if (rc == MIL_OK && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) rc = MIL_ERR_HIP;
-    if (rc == MIL_OK && max_point_lights) rc = workspace_reserve(c, 240u, 135u);      // a 3840 x 2160 frame's tiles
+    if (rc == MIL_OK && max_point_lights) rc = workspace_reserve(c, items_of(7680u, 4320u), default_pool(max_point_lights), false);
     if (rc == MIL_OK) rc = noalloc_init(c);      // the device address of the static scratch array of mil_light_ex_noalloc
     if (rc == MIL_OK) {
         uint8_t h[LUT11_N + LUT10_N];
@@ -536,6 +548,51 @@ uint32_t mil_band_local_rows(const mil_band_layout *b, uint32_t height)
     uint64_t rows = mine * b->band_rows;
     if ((nb - 1) % b->n_ranks == b->rank) rows -= nb * b->band_rows - height;       // the short last band is this rank's
     return (uint32_t)rows;
+}
+
+int mil_reserve(mil_ctx *c, uint32_t width, uint32_t height)
+{
+    if (!c || width == 0 || height == 0 || (uint64_t)width * height > (1ull << 30)) return MIL_ERR_BAD_ARG;
+    if (c->max_point == 0) return MIL_OK;               // no point lights, no tile lists
+    int rc = set_device(c);
+    if (rc) return rc;
+    return workspace_reserve(c, items_of(width, height), c->ws.pool_cap ? c->ws.pool_cap : default_pool(c->max_point), false);
+}
+
+int mil_set_list_pool(mil_ctx *c, uint32_t entries)
+{
+    if (!c || entries == 0 || entries > (1u << 30)) return MIL_ERR_BAD_ARG;
+    if (c->max_point == 0) return MIL_OK;
+    int rc = set_device(c);
+    if (rc) return rc;
+    TileWorkspace &w = c->ws;
+    if (entries == w.pool_cap) return MIL_OK;
+    if (w.pinned) return MIL_ERR_CAPACITY;
+    const uint32_t items = w.items_cap ? w.items_cap : items_of(7680u, 4320u);
+    // a smaller pool is a new allocation too: drop the old one first (hipFree waits for its kernels)
+    if (w.base) { HIP_TRY(c, hipFree(w.base)); w.base = nullptr; w.items_cap = 0; w.pool_cap = 0; }
+    return workspace_reserve(c, items, entries, false);
+}
+
+int mil_workspace_info(mil_ctx *c, mil_workspace_stats *out)
+{
+    if (!c || !out) return MIL_ERR_BAD_ARG;
+    int rc = set_device(c);
+    if (rc) return rc;
+    const TileWorkspace &w = c->ws;
+    memset(out, 0, sizeof(*out));
+    out->bytes = (uint64_t)w.bytes;
+    out->half_tiles = w.items_cap; out->pool_entries = w.pool_cap; out->list_entries_max = w.list_cap;
+    out->frame_call_allocations = w.frame_call_allocs;
+    if (w.base && w.used) {
+        HIP_TRY(c, hipEventSynchronize(w.done));
+        uint32_t v[32 * (MIL_WS_POOL_PARTS + 2)];
+        HIP_TRY(c, hipMemcpy(v, w.total, sizeof(v), hipMemcpyDeviceToHost));
+        out->last_items = v[0];
+        for (uint32_t k = 0; k < MIL_WS_POOL_PARTS; k++) out->last_pool_entries += v[32 * (1 + k)];
+        out->last_brute_macro_tiles = v[32 * (1 + MIL_WS_POOL_PARTS)];
+    }
+    return MIL_OK;
 }
 
 int mil_sync(mil_ctx *c, void *stream)
@@ -659,23 +716,32 @@ int milhost::shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_dat
     const bool many = n_point >= two_min;
     bool two = tiled && many && !strict && !(flags & MIL_FLAG_NO_CULL) && !p.shadow_lds && (!p.tile_stamps || (c->tune & 2048u)) && !(c->tune & 1024u);
     if (two) {
-        if (pre)          // the entry point that allocates nothing never grows the workspace
-            two = 2u * n_tiles <= c->ws.items_cap && ((n_tiles + MIL_WS_SHARDS - 1u) / MIL_WS_SHARDS) * 2u <= c->ws.seg_cap;
-        else if ((rc = workspace_reserve(c, p.tiles_x, p.tiles_y))) return rc;
+        const uint32_t items = 2u * n_tiles;
+        if (pre || c->ws.pinned)      // the entry point that allocates nothing never grows the workspace; a pinned one is never freed
+            two = items <= c->ws.items_cap;
+        else if ((rc = workspace_reserve(c, items, c->ws.pool_cap ? c->ws.pool_cap : default_pool(c->max_point), true))) return rc;
     }
     if (two) {
         TileWorkspace &w = c->ws;
-        if (!pre && w.used && w.last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, w.done, 0));      // one workspace per context
-        p.ws_shard_count = w.shard_count; p.ws_total = w.total; p.ws_shard_items = w.shard_items; p.ws_order = w.order;
-        p.ws_meta = w.meta; p.ws_lists = w.lists;
-        p.ws_items_cap = w.items_cap; p.ws_seg_cap = w.seg_cap;
+        // One workspace per context: a launch on another stream than the last one waits for it.  Under stream capture
+        // (mil_light_ex_noalloc inside hipStreamBeginCapture) events of the outside world may not be waited for or recorded:
+        // the captured launch stays outside this protocol - replaying the graph beside other shading calls of the same
+        // context is the caller's to order - and the workspace is pinned, because the graph holds its pointers.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (pre && s && hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+        const bool capturing = cap != hipStreamCaptureStatusNone;
+        if (capturing) w.pinned = true;
+        if (!capturing && w.used && w.last_stream != s) HIP_TRY(c, hipStreamWaitEvent(s, w.done, 0));
+        p.ws_hist = w.hist; p.ws_rank = w.rank; p.ws_total = w.total; p.ws_pool_used = w.pool_used; p.ws_order = w.order;
+        p.ws_meta = w.meta; p.ws_pool = w.pool;
+        p.ws_items_cap = w.items_cap; p.ws_pool_cap = w.pool_cap;
         const uint32_t want = (n_point + 63u) & ~63u;
-        p.ws_list_stride = want < w.list_stride_max ? want : w.list_stride_max;
-        HIP_TRY(c, hipMemsetAsync(w.shard_count, 0, (size_t)MIL_WS_SHARDS * MIL_WS_BUCKETS * 4 + 256, s));
+        p.ws_list_cap = want < w.list_cap ? want : w.list_cap;
+        HIP_TRY(c, hipMemsetAsync(w.hist, 0, WS_COUNTER_BYTES, s));
         le = mil::fast::launch_bin((int)fmt, p, s);
         if (le == hipSuccess) le = mil::fast::launch_order(p, s);
         if (le == hipSuccess) le = mil::fast::launch_shade((int)fmt, p, whole, s);
-        if (le == hipSuccess && !pre) {
+        if (le == hipSuccess && !capturing) {
             HIP_TRY(c, hipEventRecord(w.done, s));
             w.used = true; w.last_stream = s;
         }

@@ -1508,11 +1508,18 @@ DEV uint32_t wave_incl_prefix(uint32_t v, uint32_t lane)
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries a fence that also waits for every outstanding
+// global access of the wave (vmcnt(0)) - here that would put the round trip of the rank atomics in front of the barrier
+// instead of beside the pool allocation's.
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt)
 {
     __shared__ uint16_t s_coarse[COARSE_CAP];
+    __shared__ uint16_t s_list[BIN_WAVES][2][MIL_WS_LIST_MAX];     // the two half-tile lists of every wave, built here, copied out compact
     __shared__ float s_box[BIN_WAVES][6];
     __shared__ uint32_t s_cnt[64];
+    __shared__ uint32_t s_off[2 * BIN_WAVES];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t macros_x = (p.tiles_x + BIN_TX - 1) / BIN_TX;
@@ -1630,12 +1637,12 @@ __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt
         }
     }
 
-    // ---- level 2: this wave's two half-tile boxes against the survivors (or against all lights), lists in ascending order
-    const uint32_t src_n = coarse ? coarse_n : n_point, stride = p.ws_list_stride;
+    // ---- level 2: this wave's two half-tile boxes against the survivors (or against all lights), lists in ascending order, in LDS
+    const uint32_t src_n = coarse ? coarse_n : n_point, cap = p.ws_list_cap;
     const uint32_t idA = 2u * (tyi * p.tiles_x + txi);
     uint32_t lenA = 0, lenB = 0, cntU = 0;
+    uint16_t *const listA = s_list[wv][0], *const listB = s_list[wv][1];
     if (anyA || anyB) {
-        uint16_t *const listA = p.ws_lists + (size_t)idA * stride, *const listB = listA + stride;
 #pragma unroll 1
         for (uint32_t b0 = 0; b0 < src_n; b0 += 256u) {
             uint32_t li4[4];
@@ -1654,61 +1661,106 @@ __global__ __launch_bounds__(1024) void k_bin(const ShadeParams p, const int fmt
                 const unsigned long long mA = __builtin_amdgcn_ballot_w64(pA), mB = __builtin_amdgcn_ballot_w64(pB);
                 const uint32_t posA = lenA + __builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
                 const uint32_t posB = lenB + __builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
-                if (pA && posA < stride) listA[posA] = (uint16_t)li4[u];
-                if (pB && posB < stride) listB[posB] = (uint16_t)li4[u];
+                if (pA && posA < cap) listA[posA] = (uint16_t)li4[u];
+                if (pB && posB < cap) listB[posB] = (uint16_t)li4[u];
                 lenA += (uint32_t)__builtin_popcountll(mA); lenB += (uint32_t)__builtin_popcountll(mB);
                 cntU += (uint32_t)__builtin_popcountll(mA | mB);
             }
         }
     }
-    // ---- append the lit half tiles to their cost buckets (one returning add per item on the tile's shard of the counters)
-    if (lane == 0 && (itemA || itemB)) {
-        const uint32_t tile = tyi * p.tiles_x + txi, shard = tile % MIL_WS_SHARDS;
-        uint32_t *const seg = p.ws_shard_items + (size_t)shard * MIL_WS_BUCKETS * p.ws_seg_cap;
-        if (itemA) {
-            const bool brute = lenA > stride;             // more lights reach the half tile than a list holds: brute force there
-            const uint32_t b = cost_bucket(lenA, brute);
-            p.ws_meta[idA] = brute ? MIL_WS_BRUTE : lenA;
-            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = idA;
+    // ---- the macro tile's 32 lists go to the pool back to back: ONE returning atomic per workgroup.  The kernel is bound by
+    // latency, and a returning atomic on a word that all XCDs share takes 4-8 us: (a) the pool is cut into MIL_WS_POOL_PARTS
+    // partitions with a counter word (its own 128-byte line) each and a workgroup asks the partition of the XCD it runs on
+    // first (1.5-2.7 us; a full partition sends it on to the next one, so nothing depends on which XCD that is); (b) the
+    // returning adds that give the two items their rank in the launch order (k_order) are issued BEFORE the barrier, so
+    // their round trip runs under the allocation's.
+    const bool bruteA = lenA > cap, bruteB = lenB > cap;          // more lights reach the half tile than a list holds: brute force there
+    const uint32_t eA = (itemA && !bruteA) ? lenA : 0u, eB = (itemB && !bruteB) ? lenB : 0u;
+    const uint32_t tile = tyi * p.tiles_x + txi, shard = tile % MIL_WS_SHARDS;
+    const uint32_t bktA = cost_bucket(lenA, bruteA), bktB = cost_bucket(lenB, bruteB);
+    uint32_t rankA = 0, rankB = 0;
+    if (lane == 0) {
+        s_off[2 * wv] = eA; s_off[2 * wv + 1] = eB;
+        // [shard][bucket]: a shard's 32 words are one 128-byte line, so the hot buckets' words of different shards lie in
+        // different lines (laid out [bucket][shard] the 64 words of the one bucket most items fall into shared two lines and
+        // the adds serialised there: k_bin 108 us instead of 58)
+        if (itemA) rankA = atomicAdd(&p.ws_hist[shard * MIL_WS_BUCKETS + bktA], 1u);
+        if (itemB) rankB = atomicAdd(&p.ws_hist[shard * MIL_WS_BUCKETS + bktB], 1u);
+    }
+    lds_barrier();
+    if (wv == 0) {
+        const uint32_t v = lane < 2u * BIN_WAVES ? s_off[lane] : 0u;
+        const uint32_t incl = wave_incl_prefix(v, lane);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t base = MIL_WS_NONE;
+        if (total) {
+            const uint32_t part_cap = p.ws_pool_cap / MIL_WS_POOL_PARTS;
+            const uint32_t xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));           // HW_REG_XCC_ID[3:0]
+#pragma unroll 1
+            for (uint32_t k = 0; k < MIL_WS_POOL_PARTS && base == MIL_WS_NONE; k++) {
+                const uint32_t part = (xcc + k) % MIL_WS_POOL_PARTS;
+                uint32_t b = 0;
+                if (lane == 0) b = atomicAdd(&p.ws_pool_used[part * 32u], total);
+                b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                if ((uint64_t)b + total <= (uint64_t)part_cap) base = part * part_cap + b;
+            }
+            // no partition has room (mil_set_list_pool): the macro tile's half tiles are shaded by brute force
+            if (base == MIL_WS_NONE && lane == 0) atomicAdd(p.ws_pool_used + MIL_WS_POOL_PARTS * 32u, 1u);
         }
-        if (itemB) {
-            const bool brute = lenB > stride;
-            const uint32_t b = cost_bucket(lenB, brute);
-            p.ws_meta[idA + 1] = brute ? MIL_WS_BRUTE : lenB;
-            seg[(size_t)b * p.ws_seg_cap + atomicAdd(&p.ws_shard_count[shard * MIL_WS_BUCKETS + b], 1u)] = idA + 1;
+        if (lane < 2u * BIN_WAVES) s_off[lane] = base != MIL_WS_NONE ? base + (incl - v) : MIL_WS_NONE;
+    }
+    lds_barrier();
+    if (tile_in) {
+        const uint32_t offA = s_off[2 * wv], offB = s_off[2 * wv + 1];
+        if (offA != MIL_WS_NONE) {
+            for (uint32_t i = lane; i < eA; i += 64u) p.ws_pool[offA + i] = listA[i];
+            for (uint32_t i = lane; i < eB; i += 64u) p.ws_pool[offB + i] = listB[i];
+        }
+        // ---- meta of both half tiles: list length, cost bucket, brute-force flag; offset of the list
+        if (lane == 0) {
+            const bool bA = bruteA || (offA == MIL_WS_NONE && eA), bB = bruteB || (offB == MIL_WS_NONE && eB);
+            p.ws_meta[idA] = itemA ? make_uint2((bA ? MIL_WS_BRUTE : lenA) | (bktA << 16), bA ? 0u : offA) : make_uint2(MIL_WS_NONE, 0u);
+            p.ws_meta[idA + 1] = itemB ? make_uint2((bB ? MIL_WS_BRUTE : lenB) | (bktB << 16), bB ? 0u : offB) : make_uint2(MIL_WS_NONE, 0u);
+            if (itemA) p.ws_rank[idA] = rankA;
+            if (itemB) p.ws_rank[idA + 1] = rankB;
+            if (p.tile_counts) p.tile_counts[tile] = cntU;
         }
     }
-    if (lane == 0 && tile_in && p.tile_counts) p.tile_counts[tyi * p.tiles_x + txi] = cntU;
 }
 
-// k_order: one wave per (bucket, shard) segment.  The segments laid out bucket by bucket = one launch order, most expensive
-// half tiles first; ws_total = their number.  Every wave reads the whole 64 x 32 counter table (its lane = one shard's row,
-// eight 16-byte loads in flight together) and derives its own offset: no second pass, no dependence between the waves.
-__global__ __launch_bounds__(64) void k_order(const ShadeParams p)
+// k_order: a counting sort of the items by cost bucket.  Every workgroup turns the histogram (2048 words, 8 KB)
+// into exclusive segment starts in LDS (bucket-major: bucket 0, the most expensive, first), then walks its share of the
+// half tiles: an item's slot is its segment's start + the rank k_bin gave it.  No atomics.  ws_order = one launch order,
+// longest lists first; ws_total = their number.
+constexpr uint32_t ORDER_THREADS = 1024, ORDER_KEYS = MIL_WS_BUCKETS * MIL_WS_SHARDS;
+static_assert(ORDER_KEYS == 2 * ORDER_THREADS, "two histogram words per thread");
+__global__ __launch_bounds__(1024) void k_order(const ShadeParams p)
 {
-    const uint32_t lane = threadIdx.x, b = blockIdx.x / MIL_WS_SHARDS, shard = blockIdx.x % MIL_WS_SHARDS;
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4 *row = (const u4 *)(p.ws_shard_count + lane * MIL_WS_BUCKETS);      // lane = shard (MIL_WS_SHARDS = 64)
-    u4 c[MIL_WS_BUCKETS / 4];
+    __shared__ uint32_t s_start[ORDER_KEYS];
+    __shared__ uint32_t s_wave[ORDER_THREADS / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    // keys in bucket-major order (key = bucket * 64 + shard); the table itself is [shard][bucket] (see k_bin)
+    uint2 c;
+    c.x = p.ws_hist[((2 * t) % MIL_WS_SHARDS) * MIL_WS_BUCKETS + (2 * t) / MIL_WS_SHARDS];
+    c.y = p.ws_hist[((2 * t + 1) % MIL_WS_SHARDS) * MIL_WS_BUCKETS + (2 * t + 1) / MIL_WS_SHARDS];
+    const uint32_t mine = c.x + c.y;
+    const uint32_t incl = wave_incl_prefix(mine, lane);
+    if (lane == 63u) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
 #pragma unroll
-    for (int i = 0; i < (int)MIL_WS_BUCKETS / 4; i++) c[i] = row[i];
-    uint32_t before = 0, own = 0, all = 0;              // this shard's counts in buckets < b, in bucket b, in all buckets
-#pragma unroll
-    for (int i = 0; i < (int)MIL_WS_BUCKETS; i++) {
-        const uint32_t v = c[i / 4][i % 4];
-        before += (uint32_t)i < b ? v : 0u;
-        own = (uint32_t)i == b ? v : own;
-        all += v;
+    for (uint32_t k = 0; k < ORDER_THREADS / 64; k++) { const uint32_t v = s_wave[k]; before += k < wv ? v : 0u; all += v; }
+    const uint32_t excl = before + incl - mine;
+    s_start[2 * t] = excl; s_start[2 * t + 1] = excl + c.x;
+    if (blockIdx.x == 0 && t == 0) *p.ws_total = all;
+    __syncthreads();
+    const uint32_t n_items = 2u * p.tiles_x * p.tiles_y;
+    for (uint32_t i = blockIdx.x * ORDER_THREADS + t; i < n_items; i += gridDim.x * ORDER_THREADS) {
+        const uint32_t m = p.ws_meta[i].x;
+        if (m == MIL_WS_NONE) continue;
+        const uint32_t key = ((m >> 16) & (MIL_WS_BUCKETS - 1u)) * MIL_WS_SHARDS + (i >> 1) % MIL_WS_SHARDS;
+        p.ws_order[s_start[key] + p.ws_rank[i]] = i;
     }
-    const uint32_t incl_own = wave_incl_prefix(own, lane);
-    uint32_t tb = before, ta = all;                      // wave sums
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { tb += (uint32_t)__shfl_xor((int)tb, o, 64); ta += (uint32_t)__shfl_xor((int)ta, o, 64); }
-    const uint32_t mine = (uint32_t)__builtin_amdgcn_readlane((int)own, (int)shard);
-    const uint32_t dst = tb + (uint32_t)__builtin_amdgcn_readlane((int)(incl_own - own), (int)shard);
-    const uint32_t *src = p.ws_shard_items + ((size_t)shard * MIL_WS_BUCKETS + b) * p.ws_seg_cap;
-    for (uint32_t k = lane; k < mine; k += 64) p.ws_order[dst + k] = src[k];
-    if (blockIdx.x == 0 && lane == 0) *p.ws_total = ta;
 }
 
 template <int FMT, bool FRAME>
@@ -1720,7 +1772,8 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
     if (w >= *(const uint32_t *)p.ws_total) return;       // beyond the last listed half tile (the grid is the upper bound)
     const uint64_t t_start = p.tile_stamps ? __builtin_amdgcn_s_memrealtime() : 0;      // diagnostics only (100 MHz)
     const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ws_order[w]);
-    const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ws_meta[item]);
+    const uint2 meta2 = p.ws_meta[item];
+    const uint32_t meta = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta2.x), list_off = (uint32_t)__builtin_amdgcn_readfirstlane((int)meta2.y);
     const uint32_t tile = item >> 1, tyi = tile / p.tiles_x, txi = tile - tyi * p.tiles_x;
     const uint32_t x = txi * TILE + (lane & 15u), ya = tyi * TILE + (item & 1u) * 8u + (lane >> 4), yb = ya + 4;
     const uint32_t xc = min(x, p.width - 1), ylast = p.height - 1;
@@ -1732,8 +1785,8 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
     const v2f depth = { __builtin_nontemporal_load(p.depth + ia), __builtin_nontemporal_load(p.depth + ib) };
     // the list's first block of records, requested with the texels
     const bool brute = (meta & MIL_WS_BRUTE) != 0;
-    const uint32_t len = brute ? 0u : meta;
-    const uint16_t *const list = p.ws_lists + (size_t)item * p.ws_list_stride;
+    const uint32_t len = brute ? 0u : (meta & 0xFFFFu);
+    const uint16_t *const list = p.ws_pool + list_off;
     auto gather = [&](uint32_t kb, v4f &ga, v4f &gb) {
         const uint32_t li = list[min(kb + lane, len - 1)];
         ga = point_rec_a_v(p, li); gb = point_rec_b_v(p, li);
@@ -2280,7 +2333,8 @@ hipError_t launch_bin(int fmt, const ShadeParams &p, hipStream_t s)
 }
 hipError_t launch_order(const ShadeParams &p, hipStream_t s)
 {
-    return launch_k(k_order, dim3(MIL_WS_SHARDS * MIL_WS_BUCKETS), dim3(64), 0, s, p);
+    const uint32_t items = 2u * p.tiles_x * p.tiles_y, wgs = (items + ORDER_THREADS - 1) / ORDER_THREADS;
+    return launch_k(k_order, dim3(wgs < 64u ? (wgs ? wgs : 1u) : 64u), dim3(ORDER_THREADS), 0, s, p);
 }
 hipError_t launch_shade(int fmt, const ShadeParams &p, bool frame, hipStream_t s)
 {

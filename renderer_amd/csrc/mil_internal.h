@@ -29,19 +29,29 @@ struct Slot {
     uint64_t gen = 0;            // bumped whenever new content is staged into this slot
 };
 
-// Workspace of the two-kernel tiled path (k_bin -> k_shade, mil_device.hpp): per half tile a light list, its length and a
-// place in one of the cost buckets.  Sized for the largest frame the context has shaded so far: like the reference, which
-// recreates its attachments when the window is resized (render/pbr/mod.rs:263-346), a LARGER frame reallocates it (the only
-// allocation a per-frame call can make; it synchronises the device); the steady state allocates nothing.
+// Workspace of the two-kernel tiled path (k_bin -> k_order -> k_shade, mil_device.hpp): counters, the launch order and per
+// half tile {list length, list offset, rank} - sized by the frame (16 bytes per half tile) - and the POOL the compact light lists
+// live in - sized by how many (half tile, light) pairs a frame has, not by the frame.  mil_create reserves it for a
+// 7680 x 4320 frame and 2048 list entries per point light of the context's capacity (4096 lights: 16 MiB; the 8K / 4096-light
+// frame of BASELINE.json's cfg4 uses ~7 M entries): ~19 MB where rounds 1-2 reserved 133 MB for 4K and 531 MB for 8K.  No
+// per-frame call allocates for frames up to the reserved size (mil_reserve raises it ahead of time); a larger frame grows
+// the workspace inside the call once (counted in frame_call_allocs), as the reference recreates its attachments when the
+// window is resized (render/pbr/mod.rs:263-346).  A pool too small for a frame's lists costs speed, never correctness:
+// the macro tiles that found no room are shaded by the brute-force loop.
 struct TileWorkspace {
     uint8_t *base = nullptr;            // one allocation
-    uint32_t *shard_count = nullptr, *total = nullptr, *shard_items = nullptr, *order = nullptr, *meta = nullptr;
-    uint16_t *lists = nullptr;
-    uint32_t items_cap = 0, list_stride_max = 0, seg_cap = 0;
+    uint32_t *hist = nullptr, *total = nullptr, *pool_used = nullptr, *order = nullptr, *rank = nullptr;
+    uint2 *meta = nullptr;
+    uint16_t *pool = nullptr;
+    uint32_t items_cap = 0, pool_cap = 0, list_cap = 0;
+    size_t bytes = 0;
     hipEvent_t done = nullptr;          // the last launch that used it ...
     hipStream_t last_stream = nullptr;  // ... and its stream: a launch on another stream waits for it (one workspace per context)
     bool used = false;
+    bool pinned = false;                // a launch that may have been captured into a HIP graph holds these pointers: never freed again
+    uint32_t frame_call_allocs = 0;     // times a per-frame call had to grow it
 };
+constexpr size_t WS_COUNTER_BYTES = (size_t)MIL_WS_BUCKETS * MIL_WS_SHARDS * 4 + 128 + (MIL_WS_POOL_PARTS + 1) * 128;   // hist; total; pool_used per partition + brute count, 128 bytes apart
 
 constexpr int ROW_ORDER_CACHE = 16;
 struct RowOrderEntry {

@@ -93,6 +93,11 @@ struct mil_mg {
     // rank 0's device: where the dealt rows of the other ranks land before they are scattered into the frame (one slice per rank)
     uint8_t *stage = nullptr;
     size_t stage_slice = 0;
+    // Recorded on rank 0's gather stream behind the scatters of a frame: the next frame's copies into the staging slices (which
+    // run on the SENDERS' gather streams with the peer-copy transport) wait for it, so a slice is never overwritten before it
+    // was scattered.  (The RCCL receives sit on rank 0's gather stream themselves and are ordered behind the scatters anyway.)
+    hipEvent_t stage_free = nullptr;
+    bool stage_free_valid = false;
 };
 
 namespace {
@@ -179,6 +184,28 @@ int create_common(mil_mg *m, const mil_mg_config *cfg)
     return MIL_OK;
 }
 
+// The staging slices on rank 0's device hold `slice` bytes per rank.  Grows only; growing waits for every transfer of every
+// local rank (peer copies into the old buffer run on the senders' gather streams) and allocates: mil_mg_reserve does it
+// ahead of the frame loop.
+int stage_reserve(mil_mg *m, size_t slice)
+{
+    if (slice <= m->stage_slice) return MIL_OK;
+    const Local *root = nullptr;
+    for (const Local &l : m->locals) if (l.rank == 0) root = &l;
+    if (!root) return MIL_OK;
+    for (Local &l : m->locals) {
+        MG_HIP(m, hipSetDevice(l.device));
+        MG_HIP(m, hipStreamSynchronize(l.gather));
+    }
+    MG_HIP(m, hipSetDevice(root->device));
+    if (m->stage) { MG_HIP(m, hipFree(m->stage)); m->stage = nullptr; m->stage_slice = 0; }
+    MG_HIP(m, hipMalloc((void **)&m->stage, slice * m->world));
+    m->stage_slice = slice;
+    m->stage_free_valid = false;
+    if (!m->stage_free) MG_HIP(m, hipEventCreateWithFlags(&m->stage_free, hipEventDisableTiming));
+    return MIL_OK;
+}
+
 // One frame: every local rank shades its rows in chunks; after each chunk the rows go to rank 0.
 //   dst_of(rank)  base of the image on rank 0's device that receives that rank's rows, indexed by FRAME rows (strips: the
 //                 assembled frame for every rank) or by the rank's own rows (frames: the rank's slot)
@@ -188,8 +215,13 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
            void *const *dst_of, uint32_t dst_pitch_px, bool strips)
 {
     if (!m || !io || !frames || !push || !dst_of) return MIL_ERR_BAD_ARG;
+    // the resolution is validated as a float (finite, integral, 1 .. 2^24) BEFORE it is converted: a NaN, negative or huge
+    // value makes the conversion itself undefined
+    for (int a = 0; a < 2; a++) {
+        const float v = push->resolution[a];
+        if (!(v >= 1.0f) || !(v <= 16777216.0f) || v != __builtin_floorf(v)) return MIL_ERR_BAD_ARG;
+    }
     const uint32_t height = (uint32_t)push->resolution[1];
-    if (!(push->resolution[1] >= 1.0f) || (float)height != push->resolution[1]) return MIL_ERR_BAD_ARG;
     const size_t bpp = bytes_per_px(fmt);
     const bool loopback = (m->cfg.flags & MIL_MG_FLAG_LOOPBACK) != 0;
     const bool use_rccl = m->cfg.transport == MIL_MG_TRANSPORT_RCCL;
@@ -235,12 +267,9 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
     for (int r = 0; r < m->world; r++) max_rows = plan[r].rows > max_rows ? plan[r].rows : max_rows;
     const size_t row_bytes = (size_t)push->resolution[0] * bpp;
     const bool staged = strips && m->cfg.band_rows != 0;
-    if (staged && root && (size_t)max_rows * row_bytes > m->stage_slice) {
-        MG_HIP(m, hipSetDevice(root->device));
-        MG_HIP(m, hipStreamSynchronize(root->gather));
-        if (m->stage) { MG_HIP(m, hipFree(m->stage)); m->stage = nullptr; m->stage_slice = 0; }
-        MG_HIP(m, hipMalloc((void **)&m->stage, (size_t)max_rows * row_bytes * m->world));
-        m->stage_slice = (size_t)max_rows * row_bytes;
+    if (staged && root) {
+        const int rc = stage_reserve(m, (size_t)max_rows * row_bytes);      // a no-op after mil_mg_reserve for this frame size
+        if (rc) return rc;
     }
 
     // ---- enqueue, chunk by chunk
@@ -323,6 +352,8 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
                 } else if (src && root) {
                     // the emulation's sender stream carries the copy; the scatter below runs on rank 0's gather stream behind it
                     hipError_t e = hipSetDevice(src->device);
+                    // the slice may still hold the previous frame's rows, not yet scattered by rank 0's gather stream
+                    if (e == hipSuccess && m->stage_free_valid && src != root) e = hipStreamWaitEvent(src->gather, m->stage_free, 0);
                     if (e == hipSuccess) e = hipMemcpyAsync(d, sp, n, hipMemcpyDeviceToDevice, src->gather);
                     if (e == hipSuccess) e = hipEventRecord(src->chunk_done[m->locals[si].chunk_done.size() - 1], src->gather);
                     if (e == hipSuccess) e = hipStreamWaitEvent(root->gather, src->chunk_done[m->locals[si].chunk_done.size() - 1], 0);
@@ -372,6 +403,11 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
         }
         scatter.clear();
     }
+    if (staged && root && m->stage_free) {          // the slices are free again once this frame's scatters have run
+        MG_HIP(m, hipSetDevice(root->device));
+        MG_HIP(m, hipEventRecord(m->stage_free, root->gather));
+        m->stage_free_valid = true;
+    }
     for (Local &l : m->locals) {
         MG_HIP(m, hipSetDevice(l.device));
         MG_HIP(m, hipEventRecord(l.gathered[l.frame_next], l.gather));
@@ -412,9 +448,10 @@ void mil_mg_destroy(mil_mg *m)
         if (l.gather) (void)hipStreamDestroy(l.gather);
         if (l.ctx) mil_destroy(l.ctx);
     }
-    if (m->stage) {
+    if (m->stage || m->stage_free) {
         for (Local &l : m->locals) if (l.rank == 0) (void)hipSetDevice(l.device);
-        (void)hipFree(m->stage);
+        if (m->stage) (void)hipFree(m->stage);
+        if (m->stage_free) (void)hipEventDestroy(m->stage_free);
     }
     delete m;
 }
@@ -526,6 +563,23 @@ int mil_mg_render_frames(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_ma
 {
     if (!m || !slots) return MIL_ERR_BAD_ARG;
     return render(m, io, frames, true, lights, push, fmt, flags, slots, slot_pitch_px, false);
+}
+
+int mil_mg_reserve(mil_mg *m, uint32_t width, uint32_t height, mil_out_format fmt)
+{
+    if (!m || width == 0 || height == 0 || width > (1u << 24) || height > (1u << 24) || (unsigned)fmt > MIL_OUT_SRGB8_BGRA_VIA_LDR) return MIL_ERR_BAD_ARG;
+    // every local rank's context: the two-kernel workspace for the rows it will shade (strips: its share; frames: a whole frame)
+    for (Local &l : m->locals) {
+        const int rc = mil_reserve(l.ctx, width, height);
+        if (rc) return rc;
+    }
+    if (m->cfg.band_rows == 0) return MIL_OK;          // contiguous strips and whole frames are received in place
+    uint32_t max_rows = 0;
+    for (int r = 0; r < m->world; r++) {
+        const uint32_t rows = rank_rows(m->cfg, m->world, r, height);
+        max_rows = rows > max_rows ? rows : max_rows;
+    }
+    return stage_reserve(m, (size_t)max_rows * width * bytes_per_px(fmt));
 }
 
 int mil_mg_sync(mil_mg *m)

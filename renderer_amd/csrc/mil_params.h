@@ -12,8 +12,10 @@ namespace mil {
 #define MIL_MAX_ROW_ORDER 288u   // tile rows of a 4608-row frame; taller frames use plain order
 #define MIL_WS_BUCKETS 32u       // cost buckets of the two-kernel tiled path
 #define MIL_WS_SHARDS 64u        // counter shards per bucket
-#define MIL_WS_LIST_MAX 1024u    // entries a half-tile list holds at most; a half tile more lights reach is shaded by brute force
+#define MIL_WS_LIST_MAX 960u     // entries a half-tile list holds at most (k_bin builds 32 of them in LDS: 60 KB, two workgroups per CU); a half tile more lights reach is shaded by brute force
+#define MIL_WS_POOL_PARTS 8u      // partitions of the list pool, one counter word (own 128-byte line) each: a workgroup asks its XCD's first
 #define MIL_WS_BRUTE 0x80000000u
+#define MIL_WS_NONE 0xFFFFFFFFu     // meta of a half tile that is not an item (no lit pixel, or outside the launch)
 
 struct ShadeParams {
     // G-buffer planes (device), see mil_gbuffer
@@ -57,18 +59,23 @@ struct ShadeParams {
     uint32_t *tile_counts;      // optional per-tile list length (diagnostics)
     uint32_t *tile_stamps;      // optional 4 x u32 per tile: start, end (100 MHz ticks), list length, HW_ID (diagnostics)
     const uint8_t *lut11, *lut10; // sRGB8 of every R11G11B10F channel code <= 1.0
-    // Two-kernel tiled path (k_bin -> k_shade; fast mode): the context's workspace (mil_internal.h TileWorkspace).  An ITEM is a
-    // 16x8 half of a 16x16 screen tile: item = 2 * (tile_y * tiles_x + tile_x) + half.
-    // k_bin appends every lit half tile to a cost bucket (0 = most expensive).  One counter word takes ~88 returning atomics
-    // per microsecond, so the counters are SHARDED (workgroup g uses shard g % MIL_WS_SHARDS, one add per workgroup and
-    // bucket); k_order then lays the segments out bucket by bucket in ws_order, which k_shade walks in launch order.
-    uint32_t *ws_shard_count;       // [MIL_WS_SHARDS][MIL_WS_BUCKETS], then ws_total: zeroed before k_bin
-    uint32_t *ws_shard_items;       // [MIL_WS_SHARDS][MIL_WS_BUCKETS][ws_seg_cap] item ids
+    // Two-kernel tiled path (k_bin -> k_order -> k_shade; fast mode): the context's workspace (mil_internal.h TileWorkspace).
+    // An ITEM is a 16x8 half of a 16x16 screen tile: item = 2 * (tile_y * tiles_x + tile_x) + half.
+    // k_bin builds every lit half tile's light list in LDS, takes ONE returning atomic per 64x64 macro tile on ws_pool_used
+    // for the 32 lists of the macro tile together and copies them to the pool back to back: the lists are compact (a 4K
+    // frame with 4096 lights holds ~2 M entries = 4 MB; rounds 1-2 reserved 2 KiB per half tile = 133 MB).  It also counts
+    // the item in the histogram [cost bucket][shard] and keeps the count it found there as the item's RANK in that segment
+    // (a returning atomic; one counter word serves ~88 of them per microsecond, so the words are sharded by tile %
+    // MIL_WS_SHARDS; bucket 0 = most expensive).  k_order turns the histogram into segment starts and writes every item to
+    // ws_order[start + rank] - no atomics: one launch order, most expensive half tiles first, which k_shade walks.
+    uint32_t *ws_hist;              // [MIL_WS_SHARDS][MIL_WS_BUCKETS] items per (shard, bucket)     } zeroed before k_bin
+    uint32_t *ws_total;             // number of listed items                                         } by one memset
+    uint32_t *ws_pool_used;         // [MIL_WS_POOL_PARTS] x 32 words apart: entries handed out per partition; then brute count }
     uint32_t *ws_order;             // [ws_items_cap] item ids, most expensive first
-    uint32_t *ws_total;             // number of listed items
-    uint32_t *ws_meta;              // [ws_items_cap] list length | MIL_WS_BRUTE
-    uint16_t *ws_lists;             // [ws_items_cap][ws_list_stride] light indices, ascending
-    uint32_t ws_items_cap, ws_list_stride, ws_seg_cap;
+    uint32_t *ws_rank;              // [ws_items_cap] the item's rank within its (bucket, shard) segment
+    uint2 *ws_meta;                 // [ws_items_cap] { list length | bucket << 16 | MIL_WS_BRUTE, or MIL_WS_NONE ; offset of the list in ws_pool }
+    uint16_t *ws_pool;              // [ws_pool_cap] light indices, every list ascending
+    uint32_t ws_items_cap, ws_list_cap, ws_pool_cap;    // ws_list_cap <= MIL_WS_LIST_MAX: a longer list marks the half tile for brute force
     // whole-frame launch (mil_shade_frame): the sky and transparency-resolve subpasses folded into the store
     uint32_t has_sky;
     uint32_t accum_pitch, reveal_pitch;

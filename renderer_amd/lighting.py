@@ -28,7 +28,7 @@ EXPORTS = ['mil_version', 'mil_strerror', 'mil_last_hip_error', 'mil_create', 'm
            'mil_light_ex', 'mil_count_pairs', 'mil_fxaa', 'mil_sky_hosek', 'mil_transparency_resolve', 'mil_shade_frame',
            'mil_transparency_accumulate', 'mil_import_external_memory', 'mil_alloc_exportable_memory',
            'mil_release_external_memory', 'mil_shade_bands', 'mil_band_local_rows', 'mil_row_weights',
-           'mil_light_ex_noalloc', 'mil_set_two_kernel_threshold']
+           'mil_light_ex_noalloc', 'mil_set_two_kernel_threshold', 'mil_reserve', 'mil_set_list_pool', 'mil_workspace_info']
 
 
 class MilError(RuntimeError):
@@ -56,6 +56,12 @@ class Extras(ctypes.Structure):            # mil_extras
 class FramePasses(ctypes.Structure):      # mil_frame_passes
     _fields_ = [('sky', ctypes.c_void_p), ('accum', ctypes.c_void_p), ('reveal', ctypes.c_void_p),
                 ('accum_pitch_px', ctypes.c_uint32), ('reveal_pitch_px', ctypes.c_uint32)]
+
+
+class WorkspaceStats(ctypes.Structure):    # mil_workspace_stats
+    _fields_ = [('bytes', ctypes.c_uint64), ('half_tiles', ctypes.c_uint32), ('pool_entries', ctypes.c_uint32),
+                ('list_entries_max', ctypes.c_uint32), ('last_items', ctypes.c_uint32), ('last_pool_entries', ctypes.c_uint32),
+                ('last_brute_macro_tiles', ctypes.c_uint32), ('frame_call_allocations', ctypes.c_uint32)]
 
 
 class BandLayout(ctypes.Structure):        # mil_band_layout
@@ -110,6 +116,9 @@ def load_library(path=LIB_PATH):
         lib.mil_count_pairs.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, u32, vp, vp]
         lib.mil_light_ex_noalloc.argtypes = lib.mil_light_ex.argtypes
         lib.mil_set_two_kernel_threshold.argtypes = [vp, u32]
+        lib.mil_reserve.argtypes = [vp, u32, u32]
+        lib.mil_set_list_pool.argtypes = [vp, u32]
+        lib.mil_workspace_info.argtypes = [vp, ctypes.POINTER(WorkspaceStats)]
         lib.mil_shade_bands.argtypes = [vp, ctypes.POINTER(GBuffer), vp, vp, vp, ctypes.POINTER(Extras),
                                         ctypes.POINTER(FramePasses), ctypes.POINTER(BandLayout), vp, u32, ctypes.c_int,
                                         ctypes.c_int, u32, vp]
@@ -170,6 +179,20 @@ class LightingPass:
     def set_two_kernel_threshold(self, min_point_lights):
         """mil_set_two_kernel_threshold: 1 = every culled fast-mode launch goes k_bin -> k_shade, 0xFFFFFFFF = none does."""
         self._check(self.lib.mil_set_two_kernel_threshold(self.ctx, min_point_lights))
+
+    def reserve(self, width, height):
+        """mil_reserve: no per-frame call allocates for frames up to this size."""
+        self._check(self.lib.mil_reserve(self.ctx, width, height))
+
+    def set_list_pool(self, entries):
+        """mil_set_list_pool: light-list entries the two-kernel form's pool holds."""
+        self._check(self.lib.mil_set_list_pool(self.ctx, entries))
+
+    def workspace_info(self):
+        """mil_workspace_info as a dict (waits for the last two-kernel launch)."""
+        st = WorkspaceStats()
+        self._check(self.lib.mil_workspace_info(self.ctx, ctypes.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in WorkspaceStats._fields_}
 
     def close(self):
         if getattr(self, 'ctx', None):

@@ -123,11 +123,65 @@ def test_two_kernel_strips_bands_pitch_and_streams(two, one):
     outs = [two.light_ex(gb, frame, dl, pl, AMB, sh, stream=streams[i % 2]) for i in range(6)]
     torch.cuda.synchronize()
     assert all(same(o, full) for o in outs)
-    # a frame larger than the 4K reservation: the workspace is reallocated, then smaller frames again
+    # a frame larger than 4K: inside the 7680 x 4320 reservation of mil_create, nothing is allocated; then smaller frames again
     gb2, frame2, dl2, pl2, _ = scene('sweep', 4096, 2304, 64, 0)
     a = two.light_ex(gb2, frame2, dl2, pl2, AMB, None, fmt=lighting.OUT_LDR)
     assert same(a, one.light_ex(gb2, frame2, dl2, pl2, AMB, None, fmt=lighting.OUT_LDR))
     assert same(two.light_ex(gb, frame, dl, pl, AMB, sh), full)
+    assert two.workspace_info()['frame_call_allocations'] == 0
+
+
+def test_two_kernel_workspace_is_compact_and_per_frame_calls_allocate_nothing(one):
+    """the workspace was 2 KiB per half tile (133 MB at 4K, 531 MB at 8K, grown by hipFree + hipMalloc inside a
+    frame call).  Now: 12 bytes per half tile + a pool of compact lists, reserved at mil_create for 7680 x 4320; no per-frame
+    entry point allocates up to that size (the context's own counter and hipMemGetInfo agree); a pool too small for the
+    frame's lists sends the macro tiles that found no room to the brute-force loop - same bits; a frame beyond the
+    reservation grows the workspace once, inside the call, and is counted."""
+    lp = lighting.LightingPass(0, max_point_lights=4096)
+    lp.set_two_kernel_threshold(1)
+    info = lp.workspace_info()
+    assert info['half_tiles'] == 2 * 480 * 270 and info['pool_entries'] == 8 << 20 and info['list_entries_max'] == 960
+    assert info['bytes'] <= 21.5e6, info                                   # 20.9 MB: counters + 16 B x 259 200 + 16 MiB
+    gb, frame, dl, pl, sh = scene('sweep', 3840, 2160, 4096, 0)
+    out = torch.empty((2160, 3840), dtype=torch.int32, device=DEV)
+    lp.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8, out=out)          # stages the lights (ring slot, allocated at mil_create)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        lp.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8, out=out)
+    strip = {k: (v[160:1200] if torch.is_tensor(v) else v) for k, v in gb.items()}
+    strip['y_offset'] = 160
+    lp.light_ex(strip, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8, out=out[160:1200])
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    info = lp.workspace_info()
+    assert info['frame_call_allocations'] == 0
+    assert 500_000 < info['last_pool_entries'] < 2_400_000, info          # the strip's lists (last launch): compact, a fraction of the pool
+    ref = one.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8)
+    assert same(out, ref) and info['last_brute_macro_tiles'] == 0
+    # pool too small: most macro tiles find no room and take the brute-force loop; the bits do not change
+    lp.set_list_pool(200_000)
+    got = lp.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8)
+    info = lp.workspace_info()
+    assert info['pool_entries'] == 200_000 and info['last_brute_macro_tiles'] > 100 and info['frame_call_allocations'] == 0
+    assert same(got, ref)
+    lp.set_list_pool(8 << 20)
+    assert same(lp.light_ex(gb, frame, dl, pl, AMB, None, fmt=lighting.OUT_SRGB8), ref)
+    # beyond the reservation (a 16-pixel-wide frame of 2.08 M rows has more half tiles than 7680 x 4320): grows once, counted
+    h = 16 * 130_001
+    g = torch.Generator(device=DEV).manual_seed(1)
+    tall = dict(normal=torch.randint(0, 1 << 30, (h, 16), dtype=torch.int32, device=DEV, generator=g),
+                albedo_occ=torch.randint(-(1 << 31), (1 << 31) - 1, (h, 16), dtype=torch.int32, device=DEV, generator=g),
+                rough_metal=torch.randint(0, 1 << 16, (h, 16), dtype=torch.int32, device=DEV, generator=g),
+                depth=torch.rand((h, 16), dtype=torch.float32, device=DEV, generator=g), width=16, height=h, y_offset=0)
+    frame_t = synth.sweep_camera(16, h).frame_matrix_data()
+    a = lp.light_ex(tall, frame_t, dl, pl[:64], AMB, None, fmt=lighting.OUT_LDR)
+    assert lp.workspace_info()['frame_call_allocations'] == 1 and lp.workspace_info()['half_tiles'] == 2 * 130_001
+    assert same(a, one.light_ex(tall, frame_t, dl, pl[:64], AMB, None, fmt=lighting.OUT_LDR))
+    a = lp.light_ex(tall, frame_t, dl, pl[:64], AMB, None, fmt=lighting.OUT_LDR)
+    assert lp.workspace_info()['frame_call_allocations'] == 1
+    lp.reserve(7680, 4320)                                                 # already held: a no-op
+    lp.close()
 
 
 def test_two_kernel_fast_tolerance_and_noalloc(two, coracle):

@@ -70,3 +70,24 @@ def test_band_layout_rejects_bad_values():
     assert lighting.band_local_rows(100, 24, 2, 0) == 0        # band_rows must be a power of two >= 16
     assert lighting.band_local_rows(100, 8, 2, 0) == 0
     assert lighting.band_local_rows(100, 16, 2, 2) == 0        # rank < n_ranks
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_fails_cleanly_without_a_gpu():
+    """the driver runs `python bench.py --gpus N` as is.  Outside a launcher bench.py must start the N ranks
+    itself (child processes, before any GPU call) and relay rank 0's line; on a machine without a GPU every rank ends with
+    MIL_ERR_NO_DEVICE, the exit code is non-zero and stdout carries no line (there is no CPU path to fall back to)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a machine with fewer than two GPUs')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MIL_BENCH_REHEARSE')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = r.stderr.decode(errors='replace')
+    assert r.returncode != 0
+    assert r.stdout.strip() == b''
+    assert 'starting 2 ranks as child processes' in err and 'torch.distributed.run' in err
+    assert 'MIL_ERR_NO_DEVICE' in err

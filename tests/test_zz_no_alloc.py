@@ -90,3 +90,61 @@ def test_noalloc_equals_light_ex_on_two_calls_in_a_row():
     assert torch.equal(a.view(torch.int32), lp.light_ex(gb, frame, dl, pl, AMB, None).view(torch.int32))
     small.close()
     lp.close()
+
+
+def test_noalloc_two_kernel_lists_two_streams_and_graph_capture():
+    """(1) the two-kernel path of the entry point on REAL lists (capacity 4096, threshold 1, 300 lights: k_bin's
+    lists are read through the static array's cull / prepared records), == mil_light_ex bit for bit; (2) it alternates with
+    mil_light_ex of the same context on another stream (one workspace per context: the calls are serialised by the
+    workspace's event, which the entry point waits for and records - neither allocates); (3) the use it exists for: the
+    call is captured into a HIP graph and replayed; hipMemGetInfo does not move across the calls."""
+    lp = lighting.LightingPass(0, max_point_lights=4096)
+    lp.set_two_kernel_threshold(1)
+    gb, frame, dl, pl, sh = scene(320, 180, 300, 128, 11)
+    pl_dev = torch.from_numpy(pl).to(DEV)
+    want = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    out = torch.empty_like(want)
+    lp.light_ex_noalloc(gb, frame, dl, pl_dev, AMB, sh, out=out)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        out.fill_(-1.0)
+        lp.light_ex_noalloc(gb, frame, dl, pl_dev, AMB, sh, out=out)
+        assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+    assert torch.cuda.mem_get_info()[0] == free0 and lp.workspace_info()['frame_call_allocations'] == 0
+    assert lp.workspace_info()['last_pool_entries'] > 0                     # lists were built: not the brute-force fallback
+    # (2) two streams, alternating entry points, a second scene so that a stale workspace would show
+    gb2, frame2, dl2, pl2, _ = scene(256, 144, 500, 0, 12)
+    pl2_dev = torch.from_numpy(pl2).to(DEV)
+    want2 = lp.light_ex(gb2, frame2, dl2, pl2, AMB, None)
+    sa, sb = torch.cuda.Stream(device=DEV), torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(6):
+        o1, o2 = torch.empty_like(want), torch.empty_like(want2)
+        lp.light_ex(gb, frame, dl, pl, AMB, sh, out=o1, stream=sa)
+        lp.light_ex_noalloc(gb2, frame2, dl2, pl2_dev, AMB, None, out=o2, stream=sb)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1.view(torch.int32), want.view(torch.int32)) and torch.equal(o2.view(torch.int32), want2.view(torch.int32))
+    # (3) under capture: nothing is allocated, waited for or recorded outside the graph; the replay writes the same bits
+    out.fill_(-1.0)
+    graph = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream(device=DEV)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=cs):
+        lp.light_ex_noalloc(gb, frame, dl, pl_dev, AMB, sh, out=out, stream=cs)
+    torch.cuda.synchronize()
+    assert torch.all(out == -1.0)                                            # captured, not run
+    for _ in range(2):
+        out.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out.view(torch.int32), want.view(torch.int32))
+    # the workspace is pinned now: it may not move under the graph
+    with pytest.raises(lighting.MilError, match='-5'):
+        lp.set_list_pool(1 << 20)
+    assert torch.equal(lp.light_ex(gb, frame, dl, pl, AMB, sh).view(torch.int32), want.view(torch.int32))
+    del graph
+    lp.close()
