@@ -400,6 +400,8 @@ def run_mg(args, torch, dist, world, rank, local_rank):
         else:
             slots = [[torch.zeros((h, w), dtype=torch.int32, device=dev) for _ in range(world)] for _ in range(n_sets)]
 
+    mg.reserve(w, h, lighting.OUT_SRGB8)     # staging area + workspaces ahead of the loop: no per-frame call allocates
+
     def step(i):
         s = i % n_sets
         if strips:
@@ -593,6 +595,8 @@ def main():
     force_mg = os.environ.get('MIL_BENCH_FORCE_MG') == '1'       # smoke test of the mil_mg bench path with a world of one
     if world > 1 or force_mg:
         import torch.distributed as dist
+        if force_mg and 'RANK' not in os.environ:          # world of one without a launcher: the rendezvous is with oneself
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ.get('MASTER_PORT', '29531'))
         if rehearse:
             dist.init_process_group('gloo')
         else:

@@ -328,9 +328,9 @@ int mil_set_two_kernel_threshold(mil_ctx *ctx, uint32_t min_point_lights);
 /* The two-kernel form's workspace.  NO COUNTERPART IN THE REFERENCE beyond this: its attachments are allocated when the
  * window is created and recreated on a resize (render/pbr/mod.rs:98-261, 263-346), never inside Frame::build; likewise no
  * per-frame entry point of this library allocates for frames up to the reserved size.  mil_create (max_point_lights > 0)
- * reserves 16 bytes per half tile of a 7680 x 4320 frame + a POOL of 2048 light-list entries (2 bytes) per point light of
- * the capacity, clamped to 1 Mi .. 8 Mi entries: 20.9 MB for 4096 lights (the 8K / 4096-light frame of BASELINE.json uses
- * ~7 M entries, the 4K one ~2 M).
+ * reserves 16 bytes per half tile of a 7680 x 4320 frame + a POOL of 3072 light-list entries (2 bytes) per point light of
+ * the capacity, clamped to 1 Mi .. 16 Mi entries: 29.3 MB for 4096 lights (the 8K / 4096-light frame of BASELINE.json asks
+ * for 7.65 M entries, the 4K one for 2.2 M).
  *   mil_reserve        make per-frame calls on frames up to width x height allocation-free (call it where the reference
  *                      recreates its attachments); a larger frame still works: the call grows the workspace once
  *                      (hipFree + hipMalloc: waits for the device; counted in frame_call_allocations).

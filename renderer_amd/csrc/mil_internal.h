@@ -32,8 +32,8 @@ struct Slot {
 // Workspace of the two-kernel tiled path (k_bin -> k_order -> k_shade, mil_device.hpp): counters, the launch order and per
 // half tile {list length, list offset, rank} - sized by the frame (16 bytes per half tile) - and the POOL the compact light lists
 // live in - sized by how many (half tile, light) pairs a frame has, not by the frame.  mil_create reserves it for a
-// 7680 x 4320 frame and 2048 list entries per point light of the context's capacity (4096 lights: 16 MiB; the 8K / 4096-light
-// frame of BASELINE.json's cfg4 uses ~7 M entries): ~19 MB where rounds 1-2 reserved 133 MB for 4K and 531 MB for 8K.  No
+// 7680 x 4320 frame and 3072 list entries per point light of the context's capacity (4096 lights: 24 MiB; the 8K / 4096-light
+// frame of BASELINE.json's cfg4 asks for 7.65 M entries): 29 MB where rounds 1-2 reserved 133 MB for 4K and 531 MB for 8K.  No
 // per-frame call allocates for frames up to the reserved size (mil_reserve raises it ahead of time); a larger frame grows
 // the workspace inside the call once (counted in frame_call_allocs), as the reference recreates its attachments when the
 // window is resized (render/pbr/mod.rs:263-346).  A pool too small for a frame's lists costs speed, never correctness:

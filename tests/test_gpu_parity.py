@@ -793,14 +793,35 @@ def test_4k_properties(lp):
                       full_height=h, max_bad_frac=1e-3)
 
 
-def test_8k_4096_lights_properties(lp):
+def test_8k_4096_lights_properties(lp, coracle):
     """BASELINE.json configs[3] at full size (7680x4320, 4096 point lights, more than one culling chunk per tile):
-    culled == brute force bit for bit, strip-sharded (8 strips on 16-row cuts) == monolithic, fused sRGB8 == unfused."""
+    culled == brute force bit for bit, strip-sharded (8 strips on 16-row cuts) == monolithic, fused sRGB8 == unfused; and
+    against the ORACLES at that size: a 16-row band through the sphere wall of the two-kernel launch within
+    north_star's bar of the float64 oracle, the strict launch on the same band == the C oracle bit for bit."""
     from renderer_amd import sharding
     w, h = 7680, 4320
     gb, frame, dl, pl, sh = make_scene('sweep', w, h, n_point=4096, shadow=2048)
-    a = lp.light_ex(gb, frame, dl, pl, AMB, sh)
+    a = lp.light_ex(gb, frame, dl, pl, AMB, sh)                                # k_bin -> k_order -> k_shade (4096 >= the threshold)
     assert torch.isfinite(a).all() and torch.all(a[..., 3] == 1)
+    assert lp.workspace_info()['last_items'] > 100_000 and lp.workspace_info()['last_brute_macro_tiles'] == 0
+    per_band = (((gb['albedo_occ'] >> 24) & 0xFF) != 0).sum(1).view(-1, 16).sum(1)
+    full_band = int(torch.argmax(per_band).item()) * 16                        # a band where (nearly) every pixel is lit: floor + spheres
+    for yb0 in (2112, full_band):                                              # 2112: across the sphere wall at the horizon
+        yb1 = yb0 + 16
+        band = {k: (v[yb0:yb1] if torch.is_tensor(v) else v) for k, v in gb.items()}
+        band['y_offset'] = yb0
+        planes = planes_np(band)
+        kw = dict(point_lights=pl, ambient=AMB, shadow=sh_np(sh), y_offset=yb0, full_height=h)
+        r64 = coracle.shade_f64(*planes, frame, dl, **kw)
+        got = a[yb0:yb1].cpu().numpy()
+        err = np.abs(got[..., :3].astype(np.float64) - r64[..., :3])
+        bad = (err > 1e-3 + 1e-4 * np.abs(r64[..., :3])).any(-1)
+        lit = ((planes[1] >> 24) != 0).mean()
+        print(f'8K / 4096 lights, rows {yb0}..{yb1} of the two-kernel frame vs float64: {int(bad.sum())} of {bad.size} pixels outside the bare bar '
+              f'(PCF taps on the bias), max err {err.max():.3g}; {lit:.0%} of the band lit')
+        assert lit > (0.9 if yb0 == full_band else 0.15) and bad.sum() <= 16
+        strict = lp.light_ex(band, frame, dl, pl, AMB, sh, flags=lighting.FLAG_STRICT).cpu().numpy()
+        assert_bits_equal(strict, coracle.shade(*planes, frame, dl, **kw), f'8K band {yb0} strict')
     y0, y1 = 2048, 2048 + 544                                                # brute force on one strip through the sphere wall
     strip = {k: (v[y0:y1] if torch.is_tensor(v) else v) for k, v in gb.items()}
     strip['y_offset'] = y0
