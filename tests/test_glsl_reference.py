@@ -102,3 +102,40 @@ def test_fixture_regenerates_from_the_reference_source(ref, tmp_path, monkeypatc
     sw = np.load(os.path.join(GOLDEN, 'sweep_96x54.npz'))
     hdr, _ = m.lighting(sw)
     assert bits_equal(hdr, ref['hdr_sweep'])
+
+
+# ---- HosekWilkieParams blocks the reference itself would produce (tests/golden/make_hosek_golden.py)
+@pytest.fixture(scope='module')
+def hosek():
+    return np.load(os.path.join(GOLDEN, 'hosek_params.npz'))
+
+
+@pytest.mark.parametrize('name', ['default', 'basic'])
+def test_sky_shader_on_reference_coefficient_blocks(hosek, coracle, name):
+    """The sky of HosekSky::new (sun at the zenith, turbidity 1) and of scenes/basic.rs (sun = light 0, turbidity 8, red
+    ground): make_hosek_wilkie_params evaluated on the reference's dataset.rs, then the reference's sky_hosek_frag.glsl
+    executed on it - the C oracle reproduces that image bit for bit, the float64 oracle to 1e-5."""
+    sw = np.load(os.path.join(GOLDEN, 'sweep_96x54.npz'))
+    prm, img = hosek['params_' + name], hosek['sky_hdr_' + name]
+    assert prm.shape == (11, 4) and prm.dtype == np.float32 and np.all(prm[:, 3] == 0)
+    assert np.all(np.abs(prm[:10, :3] - hosek['params_' + name + '_f64'][:10, :3]) <= 2e-6 * np.abs(hosek['params_' + name + '_f64'][:10, :3]) + 1e-7)
+    assert abs(np.linalg.norm(prm[10, :3]) - 1) < 1e-6
+    hdr0 = sw['hdr_dir_only_c32']
+    got = coracle.sky_hosek(sw['depth'], sw['frame'], prm, hdr0.copy())
+    assert bits_equal(img, got)
+    sky = sw['depth'] >= 1
+    assert np.isfinite(img).all() and np.all(img[sky][:, :3] > 0) and bits_equal(img[~sky], hdr0[~sky])
+    r64 = mo.sky_hosek(sw['depth'], sw['frame'], prm, hdr0.astype(np.float64))
+    assert np.all(np.abs(r64 - img) <= 1e-5 + 1e-5 * np.abs(r64))
+    if name == 'default':       # zenith sun: elevation^(1/3) = 1, every spline is its last control point; Z = the radiance table's
+        assert np.allclose(prm[9, :3], [4.324573, 8.090833, 13.90238], rtol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir(SHADERS), reason='the reference tree exists only in the development container')
+def test_hosek_fixture_regenerates_from_the_reference_dataset(hosek):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_hosek_golden', os.path.join(GOLDEN, 'make_hosek_golden.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    for name, (sun, turb, alb) in m.parameter_sets().items():
+        assert bits_equal(m.make_params(sun, turb, alb), hosek['params_' + name]), name

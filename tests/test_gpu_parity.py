@@ -498,6 +498,39 @@ def test_sky_hosek(lp, coracle):
             assert torch.equal(lp.sky_hosek(strip, frame, prm, hdr0[y0:y1].clone(), strict=st), full[y0:y1])
 
 
+@pytest.mark.parametrize('name', ['default', 'basic'])
+def test_sky_hosek_on_reference_coefficient_blocks(lp, coracle, name):
+    """k_sky had only seen synthetic coefficients.  tests/golden/hosek_params.npz holds the blocks the reference
+    computes for HosekSky::new and for scenes/basic.rs (render/hosek/mod.rs:123-224 on its dataset.rs) and what its own
+    sky_hosek_frag.glsl, executed, makes of them: the strict kernel reproduces that image (to the last ulp of exp / pow /
+    acos, as for the synthetic block), the fast kernel is within 1e-3 + 1e-4 |x| of float64, and mil_shade_frame with that
+    sky equals the chain of separate calls bit for bit."""
+    z = np.load(os.path.join(GOLDEN, 'hosek_params.npz'))
+    g = np.load(os.path.join(GOLDEN, 'sweep_96x54.npz'))
+    prm, img = z['params_' + name], z['sky_hdr_' + name]
+    gb = {k: torch.from_numpy(g[k].view(np.int32) if g[k].dtype == np.uint32 else g[k]).to(DEV) for k in ('normal', 'albedo_occ', 'rough_metal', 'depth')}
+    gb.update(width=96, height=54, y_offset=0)
+    frame, dl = g['frame'], g['dir_lights']
+    hdr0 = lp.light_directional(gb, frame, dl, strict=True)
+    assert_bits_equal(hdr0.cpu().numpy(), g['hdr_dir_only_c32'], 'lighting under the sky')
+    strict = lp.sky_hosek(gb, frame, prm, hdr0.clone(), strict=True).cpu().numpy()
+    np.testing.assert_allclose(strict, img, rtol=3e-7, atol=0)
+    assert (strict != img).mean() < 1e-3
+    f0 = lp.light_directional(gb, frame, dl)
+    fast = lp.sky_hosek(gb, frame, prm, f0.clone()).cpu().numpy()
+    r64 = mo.sky_hosek(g['depth'], frame, prm, f0.cpu().numpy())
+    assert np.all(np.abs(fast - r64) <= 1e-3 + 1e-4 * np.abs(r64))
+    sky = g['depth'] >= 1
+    assert sky.mean() > 0.2 and np.all(fast[sky][:, :3] > 0)
+    for st in (False, True):
+        for fmt in (lighting.OUT_HDR, lighting.OUT_SRGB8):
+            chain = lp.sky_hosek(gb, frame, prm, lp.light_directional(gb, frame, dl, strict=st), strict=st)
+            if fmt != lighting.OUT_HDR:
+                chain = lp.tonemap(chain, fmt, strict=st)
+            one = lp.shade_frame(gb, frame, dl, sky=prm, fmt=fmt, flags=lighting.FLAG_STRICT if st else 0)
+            assert torch.equal(one.view(torch.int32), chain.view(torch.int32)), (name, st, fmt)
+
+
 def test_transparency_resolve(lp, coracle):
     from test_oracle_kat import transparency_test_inputs
     for (w, h) in [(256, 144), (65, 5)]:
