@@ -420,13 +420,20 @@ template <typename T> DEV void eval_light(const PxT<T> &q, V3<T> L, V3<T> col, T
     const T s2 = one_minus_ndoth2<T>(q.N, H, rh);
     eval_tail<T>(q, sat_fma(q.N.z, L.z, fma_(q.N.y, L.y, q.N.x * L.x)), s2, LdotH, col, scale, res);
 }
-// Point lights (L normalised here) take the same literal H = L + V.  The unit-length shortcut |L+V|^2 = 2 + 2 L.V,
-// N.H = (N.L + N.V) / |L+V| is six packed instructions per pair shorter (-5 % on the headline frame) but cancels when the
-// light is nearly opposite the eye (L.V -> -1): N.H lost up to ten bits there, 7 % on a mirror-like grazing highlight
-// (one pixel in ~1e8 of tools/fuzz_parity.py's random frames; the literal form has none).
+// Point lights: L and V are unit vectors here, so L.H = L.(L + V) = 1 + L.V = |H|^2 / 2 and clamp(L.H / |H|, 0, 1) =
+// |H|^2 rh / 2 - one multiply where the general form takes a dot product (three packed instructions per pair fewer).
+// |H|^2 is the literal dot(H, H) of the literal H = L + V, so nothing cancels that the literal form keeps; the two forms
+// differ by the unit-length error of L and V, ~1e-7 absolute, in a term that only enters Fresnel's (1 - L.H)^5.
+// (N.H keeps its own form, one_minus_ndoth2: the shortcut N.H = (N.L + N.V) / |H| with |H|^2 = 2 + 2 L.V of round 1
+// cancelled when the light is nearly opposite the eye and was dropped for that.)
 template <typename T> DEV void eval_light_unit(const PxT<T> &q, V3<T> L, V3<T> col, T scale, V3<T> &res)
 {
-    eval_light<T>(q, L, col, scale, res);
+    V3<T> H = { L.x + q.V.x, L.y + q.V.y, L.z + q.V.z };
+    const T hh = max_(dot3(H, H), (T)(1e-30f));
+    const T rh = rsq_(hh);
+    const T LdotH = sat_mul(hh * 0.5f, rh);
+    const T s2 = one_minus_ndoth2<T>(q.N, H, rh);
+    eval_tail<T>(q, sat_fma(q.N.z, L.z, fma_(q.N.y, L.y, q.N.x * L.x)), s2, LdotH, col, scale, res);
 }
 
 DEV void add_directional(const Px &q, DirRec d, float shadow, bool use_shadow, f3 &res)
@@ -1021,7 +1028,7 @@ DEV float box_d2(v4f a, f3 lo, f3 hi)
 }
 
 // Per-wave LDS carve of k_tiled (bytes), shared by the launcher and the kernel.
-struct TiledLds { uint32_t list, stash, shadow, resolve, per_wave; };
+struct TiledLds { uint32_t list, stash, shadow, resolve, pos, per_wave; };
 static __host__ __device__ __forceinline__ TiledLds tiled_lds(uint32_t n_point, bool stage, bool resolve)
 {
     TiledLds l;
@@ -1030,7 +1037,12 @@ static __host__ __device__ __forceinline__ TiledLds tiled_lds(uint32_t n_point, 
     l.stash = l.list + ((cap * 2u + 2u + 15u) & ~15u);              // + one dump entry behind the list (branch-free append)
     l.shadow = l.stash + (n_point > (uint32_t)CHUNK ? 768u * 4u : 0u);
     l.resolve = l.shadow + (stage ? (uint32_t)SH_CAP * 4u : 0u);
-    l.per_wave = l.resolve + (resolve ? 2560u : 0u);                  // whole frame: 256 accum texels (8 B) + 256 revealage (2 B)
+    l.pos = l.resolve + (resolve ? 2560u : 0u);                       // whole frame: 256 accum texels (8 B) + 256 revealage (2 B)
+    // fast mode: P - cameraPosition of the tile's 256 pixels, formed once for the box of the lit pixels and read back by the
+    // two shading passes (12 floats per lane) instead of being evaluated again
+    // (not beside the resolve texels of a whole-frame launch: 10 KB per wave would leave three workgroups per CU where
+    // the registers allow four, measured +9 % on mil_shade_frame; there the passes evaluate the positions again)
+    l.per_wave = l.pos + ((!MIL_STRICT && (n_point > 0u || stage) && !resolve) ? 3072u : 0u);
     return l;
 }
 
@@ -1198,6 +1210,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
     f3 lo = { INF, INF, INF }, hi = { -INF, -INF, -INF };
     int x0 = 0x7FFFFFFF, x1 = -0x7FFFFFFF, yy0 = 0x7FFFFFFF, yy1 = -0x7FFFFFFF;
     bool lit4[4];
+    bool have_pos = false;        // wave-uniform: P - cameraPosition of the tile's pixels is parked in LDS (fast mode)
 #pragma unroll
     for (int j = 0; j < 4; j++)   // occlusion 0 => every point-light term is exactly 0
         lit4[j] = xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
@@ -1211,7 +1224,12 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             const PosT<v2f> q2 = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(y0 + 4 * jj + rm.g), (float)(y0 + 4 * jj + 4 + rm.g) },
                                                        v2f{ __uint_as_float(s_tex[(12 + jj) * 64 + lane]), __uint_as_float(s_tex[(13 + jj) * 64 + lane]) });
             P4[jj] = f3{ q2.P.x.x, q2.P.y.x, q2.P.z.x }; P4[jj + 1] = f3{ q2.P.x.y, q2.P.y.y, q2.P.z.y };
+            if (L.per_wave != L.pos) {
+                v2f *park = (v2f *)(s_wave + L.pos) + (jj / 2) * 192;
+                park[lane] = q2.D.x; park[64 + lane] = q2.D.y; park[128 + lane] = q2.D.z;
+            }
         }
+        have_pos = L.per_wave != L.pos;
 #endif
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1388,8 +1406,15 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 continue;
             }
             Px2 q;
-            setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth),
-                                    u1, w2, u3);
+            PosT<v2f> pos;
+            if (have_pos) {       // the box phase evaluated this (same function, same inputs): read it back
+                const v2f *park = (const v2f *)(s_wave + L.pos) + jp * 192;
+                pos.D = V3<v2f>{ park[lane], park[64 + lane], park[128 + lane] };
+                pos.P = V3<v2f>{ pos.D.x + p.cam[0], pos.D.y + p.cam[1], pos.D.z + p.cam[2] };
+            } else {
+                pos = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth);
+            }
+            setup_pixel_t<v2f, v2u>(q, pos, u1, w2, u3);
             V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
             if (first) {
                 v2f shadow = { 1.0f, 1.0f };

@@ -7,6 +7,7 @@ case = sys.argv[1]; iters = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 W, H = 3840, 2160
 dev = 'cuda:0'
 lp = lighting.LightingPass(0, 4096)
+if os.environ.get('TWO'): lp.set_two_kernel_threshold(int(os.environ['TWO']))
 cam = synth.sweep_camera(W, H)
 gbs = [synth.scene_sweep(W, H, cam, device=dev)]
 for _ in range(2): gbs.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in gbs[0].items()})
