@@ -343,6 +343,13 @@ void order_rows(mil_ctx *c, const Slot *lights, mil::ShadeParams &p, const mil_f
     for (uint32_t lvl = wmax + 1; lvl-- > 0;)
         for (uint32_t i = R; i-- > 0;)
             if (w[i] == lvl) p.row_order[n++] = (uint16_t)i;
+    if (c->tune & 0x70000u) {          // EXPERIMENT (MIL_DEBUG=1 MIL_TUNE): launch orders that mix cheap and expensive rows
+        uint16_t s0[MIL_MAX_ROW_ORDER];
+        memcpy(s0, p.row_order, sizeof(s0));
+        if (c->tune & 0x10000u) for (uint32_t i = 0; i < R; i++) p.row_order[i] = (i & 1u) ? s0[R - 1 - i / 2] : s0[i / 2];          // heaviest, cheapest, ...
+        else if (c->tune & 0x20000u) for (uint32_t i = 0; i < R; i++) p.row_order[i] = (uint16_t)((i & 1u) ? R / 2 + i / 2 : i / 2);   // top half / bottom half alternating
+        else { uint32_t k = 0; for (uint32_t st = 0; st < 8; st++) for (uint32_t i = st; i < R; i += 8) p.row_order[k++] = s0[i]; } // stride 8 over the sorted order
+    }
     RowOrderEntry &slot = c->row_cache[c->row_cache_next];
     c->row_cache_next = (c->row_cache_next + 1) % ROW_ORDER_CACHE;
     memcpy(slot.order, p.row_order, sizeof(p.row_order));

@@ -507,6 +507,17 @@ DEV void far_if_unlit(Px2 &q)
     q.P.y = v2f{ a ? q.P.y.x : 1e30f, b ? q.P.y.y : 1e30f };
     q.P.z = v2f{ a ? q.P.z.x : 1e30f, b ? q.P.z.y : 1e30f };
 }
+// EXTENSION E4 of a pixel pair: ambient * albedo * occlusion, albedo re-decoded from the texel.  The fast kernels START their
+// sum with it (fs_deferred_lighting.glsl:61 starts from 0 and the strict kernels add the extension last, as the oracle does;
+// the order is the same in every fast kernel, so they still agree bit for bit): occlusion and the texel are then dead before
+// the light loops instead of live across them - four registers in kernels that sit at the 128-VGPR limit.
+DEV V3<v2f> ambient_start(const Px2 &q, const ShadeParams &p, v2u w2)
+{
+    if (!p.has_ambient) return V3<v2f>{ (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+    const v2f ka = q.occ * (1.0f / 255.0f);
+    return V3<v2f>{ (v2f)(p.ambient[0]) * (tof(w2 & 0xFFu) * ka), (v2f)(p.ambient[1]) * (tof((w2 >> 8) & 0xFFu) * ka),
+                    (v2f)(p.ambient[2]) * (tof((w2 >> 16) & 0xFFu) * ka) };
+}
 DEV void point_eval2(const Px2 &q, v4f b, V3<v2f> Lv, v2f d2, bool on0, bool on1, V3<v2f> &res)
 {
     v2f inv = rsq_(d2 + 1e-12f);
@@ -786,6 +797,47 @@ DEV void emit_pixel(const ShadeParams &p, uint32_t x, uint32_t y, RowMap rm, flo
     const v4f h = frame_value(p, x, y, rm, depth, res, tile);
     store_pixel<FMT>(p, x, y + rm.o, f3{ h.x, h.y, h.z }, h.w);
 }
+#if !MIL_STRICT
+// The two pixels of a lane at once (fast mode, no later subpass): the ACES fit and the sRGB OETF of encode_ldr<FMT_SRGB8> on
+// the packed pairs the shading already holds - one v_pk instruction for both pixels where the per-pixel form issues two
+// (rcp / log / exp stay per pixel).  The same operations in the same order, and packed ops round like scalar ones: the same
+// bits as emit_pixel twice (tests: fused == unfused, dual output == mil_tonemap of the stored hdr).  The constants are
+// pinned where they are used: as loop invariants the compiler held them in SGPRs across the light loops and spilled.
+DEV v2f kpin(float k) { asm volatile("" : "+s"(k)); return (v2f)(k); }
+DEV v2u srgb8_pair(v2f x)
+{
+    x = v2f{ fminf(x.x, 1.0e9f), fminf(x.y, 1.0e9f) };
+    const v2f num = x * fma_(kpin(2.51f), x, kpin(0.03f)), den = fma_(x, fma_(kpin(2.43f), x, kpin(0.59f)), kpin(0.14f));
+    const v2f c = v2f{ clampf(num.x * rcp_(den.x), 0.0f, 1.0f), clampf(num.y * rcp_(den.y), 0.0f, 1.0f) };
+    const v2f lg = v2f{ __builtin_amdgcn_logf(c.x), __builtin_amdgcn_logf(c.y) } * kpin(1.0f / 2.4f);
+    const v2f pw = fma_(kpin(1.055f), v2f{ __builtin_amdgcn_exp2f(lg.x), __builtin_amdgcn_exp2f(lg.y) }, kpin(-0.055f));
+    const v2f lin = kpin(12.92f) * c;
+    const v2f s = v2f{ c.x <= 0.0031308f ? lin.x : pw.x, c.y <= 0.0031308f ? lin.y : pw.y };
+    const v2f q = fma_(s, kpin(255.0f), (v2f)(0.5f));
+    return v2u{ (uint32_t)q.x, (uint32_t)q.y };
+}
+template <int FMT>
+DEV void emit_pair(const ShadeParams &p, uint32_t x, uint32_t ya, uint32_t yb, RowMap rm, bool inA, bool inB, V3<v2f> r)
+{
+    if (FMT == FMT_HDR || FMT == FMT_SRGB8) {
+        const size_t oa = (size_t)(ya + rm.o) * p.out_pitch + x, ob = (size_t)(yb + rm.o) * p.out_pitch + x;
+        if (FMT == FMT_HDR) {
+            if (inA) __builtin_nontemporal_store(v4f{ r.x.x, r.y.x, r.z.x, 1.0f }, (v4f *)p.out + oa);
+            if (inB) __builtin_nontemporal_store(v4f{ r.x.y, r.y.y, r.z.y, 1.0f }, (v4f *)p.out + ob);
+            if (!p.out2) return;
+        }
+        const v2u cr = srgb8_pair(r.x), cg = srgb8_pair(r.y), cb = srgb8_pair(r.z);
+        const v2u w = cb | (cg << 8) | (cr << 16) | 0xFF000000u;
+        uint32_t *const o = FMT == FMT_HDR ? p.out2 : (uint32_t *)p.out;
+        const uint32_t pitch = FMT == FMT_HDR ? p.out2_pitch : p.out_pitch;
+        if (inA) __builtin_nontemporal_store(w.x, o + (size_t)(ya + rm.o) * pitch + x);
+        if (inB) __builtin_nontemporal_store(w.y, o + (size_t)(yb + rm.o) * pitch + x);
+    } else {
+        if (inA) store_pixel<FMT>(p, x, ya + rm.o, f3{ r.x.x, r.y.x, r.z.x });
+        if (inB) store_pixel<FMT>(p, x, yb + rm.o, f3{ r.x.y, r.y.y, r.z.y });
+    }
+}
+#endif
 // the same store through pointers fetched earlier (see k_tiled's unlit tiles)
 template <int FMT>
 DEV void store_pixel_to(void *out, uint32_t out_pitch, const uint8_t *lut11, const uint8_t *lut10, uint32_t x, uint32_t y, v4f h,
@@ -811,6 +863,12 @@ DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, RowMap
     Px q;
     setup_pixel(q, p, pixel_position(p, x, y + rm.g, depth), u1, u2, u3);
     f3 res = { 0.0f, 0.0f, 0.0f };
+#if !MIL_STRICT
+    if (EXT && p.has_ambient) {        // the fast kernels start their sum with the ambient term (ambient_start)
+        const float k = q.occ * (1.0f / 255.0f);
+        res = f3{ p.ambient[0] * ((float)(u2 & 0xFF) * k), p.ambient[1] * ((float)((u2 >> 8) & 0xFF) * k), p.ambient[2] * ((float)((u2 >> 16) & 0xFF) * k) };
+    }
+#endif
     float shadow = 1.0f;
     const bool sh = EXT && p.has_shadow;
     if (sh && p.n_dir > 0) shadow = pcf_direct(shadow_tap(q.P, p), p);
@@ -822,7 +880,9 @@ DEV void shade_stream_pixel(const ShadeParams &p, uint32_t x, uint32_t y, RowMap
     }
     if (EXT) {
         for (uint32_t l = 0; l < p.n_point; l++) add_point(q, point_rec_a(p, l), point_rec_b(p, l), res);
+#if MIL_STRICT
         if (p.has_ambient) add_ambient(q, p, u2, res);
+#endif
     }
     emit_pixel<FMT, FRAME>(p, x, y, rm, depth, res);
 }
@@ -905,6 +965,7 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
     Px2 q;
     setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth), u1, w2, u3);
     V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+    if (EXT) r = ambient_start(q, p, w2);
     const bool sh = EXT && p.has_shadow && p.n_dir > 0;
     v2f shadow = { 1.0f, 1.0f };
     if (sh) {
@@ -913,9 +974,9 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
         if (litA) shadow.x = pcf_direct(ta, p);
         if (litB) shadow.y = pcf_direct(tb, p);
     }
+    if (EXT && p.n_point) far_if_unlit(q);                   // after the taps (they read P), before the loops (occlusion dies here)
     for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, sh && l == 0, r);   // fs_deferred_lighting.glsl:62-64
     if (EXT) {
-        far_if_unlit(q);
         for (uint32_t l = 0; l < p.n_point; l++) {
             const v4f a = point_rec_a(p, l);
             V3<v2f> Lv;
@@ -925,15 +986,12 @@ __global__ __launch_bounds__(256) void k_stream2(const ShadeParams p)
             const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
             point_eval2(q, point_rec_b(p, l), Lv, d2, on0, on1, r);
         }
-        if (p.has_ambient) {
-            const v2f ka = q.occ * (1.0f / 255.0f);
-            r.x = fma_((v2f)(p.ambient[0]), tof(w2 & 0xFFu) * ka, r.x);
-            r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
-            r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
-        }
     }
-    emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
-    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
+    if (!FRAME) emit_pair<FMT>(p, x, ya, yb, rm, true, inB, r);
+    else {
+        emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
+        if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
+    }
 }
 #endif
 
@@ -1416,14 +1474,18 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             }
             setup_pixel_t<v2f, v2u>(q, pos, u1, w2, u3);
             V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+            v2f shadow = { 1.0f, 1.0f };
             if (first) {
-                v2f shadow = { 1.0f, 1.0f };
+                r = ambient_start(q, p, w2);
                 if (do_shadow) {
                     ShadowTap ta, tb;
                     shadow_tap2(q.P, p, ta, tb);
                     if (litA) shadow.x = shadow_px(ta);
                     if (litB) shadow.y = shadow_px(tb);
                 }
+            }
+            if (cnt) far_if_unlit(q);                        // after the taps (they read P), before the loops (occlusion dies here)
+            if (first) {
                 for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
             } else {
                 r.x = v2f{ s_res[ja * 64 + lane], s_res[(ja + 1) * 64 + lane] };
@@ -1431,7 +1493,6 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 r.z = v2f{ s_res[512 + ja * 64 + lane], s_res[512 + (ja + 1) * 64 + lane] };
             }
             if (cnt) {
-                far_if_unlit(q);
                 uint32_t kb = 0;
 #pragma unroll 1
                 for (;;) {
@@ -1453,14 +1514,11 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 if (cnt > 64 && jp == 0) gather(0, ra, rb);
             }
             if (last) {
-                if (p.has_ambient) {
-                    const v2f ka = q.occ * (1.0f / 255.0f);       // albedo * occlusion re-decoded from the texel
-                    r.x = fma_((v2f)(p.ambient[0]), tof(w2 & 0xFFu) * ka, r.x);
-                    r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
-                    r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
+                if (!FRAME) emit_pair<FMT>(p, x, ya, yb, rm, inA, inB, r);
+                else {
+                    if (inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x }, s_resolve);
+                    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y }, s_resolve);
                 }
-                if (inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x }, s_resolve);
-                if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y }, s_resolve);
             } else {
                 s_res[ja * 64 + lane] = r.x.x; s_res[(ja + 1) * 64 + lane] = r.x.y;
                 s_res[256 + ja * 64 + lane] = r.y.x; s_res[256 + (ja + 1) * 64 + lane] = r.y.y;
@@ -1829,7 +1887,7 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
 
     Px2 q;
     setup_pixel_t<v2f, v2u>(q, pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth), u1, w2, u3);
-    V3<v2f> r = { (v2f)(0.0f), (v2f)(0.0f), (v2f)(0.0f) };
+    V3<v2f> r = ambient_start(q, p, w2);
     const bool do_shadow = p.has_shadow && p.n_dir > 0;
     v2f shadow = { 1.0f, 1.0f };
     if (do_shadow) {
@@ -1838,8 +1896,8 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
         if (litA) shadow.x = pcf_direct(ta, p);
         if (litB) shadow.y = pcf_direct(tb, p);
     }
+    far_if_unlit(q);                                         // after the taps (they read P), before the loops (occlusion dies here)
     for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
-    far_if_unlit(q);
     if (len) {
         uint32_t kb = 0;
 #pragma unroll 1
@@ -1871,14 +1929,11 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
             point_eval2(q, point_rec_b(p, l), Lv, d2, on0, on1, r);
         }
     }
-    if (p.has_ambient) {
-        const v2f ka = q.occ * (1.0f / 255.0f);           // albedo * occlusion re-decoded from the texel
-        r.x = fma_((v2f)(p.ambient[0]), tof(w2 & 0xFFu) * ka, r.x);
-        r.y = fma_((v2f)(p.ambient[1]), tof((w2 >> 8) & 0xFFu) * ka, r.y);
-        r.z = fma_((v2f)(p.ambient[2]), tof((w2 >> 16) & 0xFFu) * ka, r.z);
+    if (!FRAME) emit_pair<FMT>(p, x, ya, yb, rm, inA, inB, r);
+    else {
+        if (inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
+        if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
     }
-    if (inA) emit_pixel<FMT, FRAME>(p, x, ya, rm, depth.x, f3{ r.x.x, r.y.x, r.z.x });
-    if (inB) emit_pixel<FMT, FRAME>(p, x, yb, rm, depth.y, f3{ r.x.y, r.y.y, r.z.y });
     if (p.tile_stamps && lane == 0) {                     // diagnostics (MIL_TUNE bit 2048): per ITEM start, end, list length, launch index
         uint32_t *st = p.tile_stamps + 4 * (size_t)item;
         st[0] = (uint32_t)t_start; st[1] = (uint32_t)__builtin_amdgcn_s_memrealtime(); st[2] = brute ? 0xFFFFu : len; st[3] = w;
