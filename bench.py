@@ -51,7 +51,7 @@ WORKLOADS = {
 }
 
 
-TWO_KERNEL_MIN = 1024     # include/mil.h MIL_TWO_KERNEL_DEFAULT: point lights from which mil_light_ex takes k_bin -> k_shade
+TWO_KERNEL_MIN = 1280     # include/mil.h MIL_TWO_KERNEL_DEFAULT: point lights from which mil_light_ex takes k_bin -> k_shade
 
 
 def parse():
@@ -489,7 +489,7 @@ def run_mg(args, torch, dist, world, rank, local_rank):
             res['config']['assembled_equals_single_gpu_bitwise'] = equal
             res['config']['note'] = ('the N = 1 default line of this bench is BASELINE.json\'s metric configuration (4K, 256 lights, two kernels): '
                                      'compare this value with config.one_gpu_same_workload, not with that line')
-        # roofline of the lighting launch over this rank's rows (from 1024 point lights on: k_bin, k_order and k_shade together;
+        # roofline of the lighting launch over this rank's rows (from 1280 point lights on: k_bin, k_order and k_shade together;
         # k_shade is > 85 % of it), HIP-event burst on its stream
         if lrows:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -231,7 +231,7 @@ int mil_light_ex(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_dat
  *   - the staging buffer is a static __device__ array of the library (334 080 bytes per GPU, held until the process
  *     ends) instead of the context's ring.  The call makes no hipMalloc / hipFree / hipMemcpy and creates nothing.  It
  *     enqueues on `stream`: k_prepare_lights (when there are point lights or more than 4 directional ones), then ONE
- *     shading kernel (k_stream2 / k_tiled), or from the context's two-kernel threshold on (1024 point lights) a
+ *     shading kernel (k_stream2 / k_tiled), or from the context's two-kernel threshold on (1280 point lights) a
  *     hipMemsetAsync of 8.4 KB of workspace counters + k_bin + k_order + k_shade.  Every call on one GPU shares that
  *     array: calls that OVERLAP on one GPU (two streams, two threads, two contexts) race - serialise them.  The K2 launch
  *     order is the plain one (the host never sees the lights); speed only;
@@ -322,7 +322,7 @@ int mil_count_pairs(mil_ctx *ctx, const mil_gbuffer *gb, const mil_frame_matrix_
  * k_shade: one wave per listed half tile, most expensive first), the others the one-kernel form (k_tiled); results are
  * bit-identical.  Default MIL_TWO_KERNEL_DEFAULT (measured crossover on a 4K frame); 1 = always, 0xFFFFFFFF = never.
  * One workspace per context: launches of one context on different streams are serialised. */
-#define MIL_TWO_KERNEL_DEFAULT 1024u
+#define MIL_TWO_KERNEL_DEFAULT 1280u
 int mil_set_two_kernel_threshold(mil_ctx *ctx, uint32_t min_point_lights);
 
 /* The two-kernel form's workspace.  NO COUNTERPART IN THE REFERENCE beyond this: its attachments are allocated when the
