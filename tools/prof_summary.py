@@ -10,6 +10,16 @@ for f in glob.glob(f'{O}/stats/**/*kernel_stats.csv', recursive=True):
     for r in rows:
         if 'mil::' not in r['Name'] and float(r['Percentage']) < 2.0: continue
         out.append(f'{r["Name"][:70]:70s} {r["Calls"]:>6s} {float(r["AverageNs"])/1e3:10.2f} {float(r["MinNs"])/1e3:10.2f} {float(r["MaxNs"])/1e3:10.2f} {float(r["Percentage"]):6.2f}')
+# --- the same kernels per workload: one tools/run_case.py case per rocprofv3 run
+out.append('')
+out.append('# rocprofv3 --kernel-trace --stats -- python3 tools/run_case.py <case> 12   (one workload per run: 4K Scene A; headline / dual: 2 dir + PCF 2048^2 +')
+out.append('# 256 point + ambient, hdr / hdr + sRGB8; l4096: the same with 4096 point lights; k1: 1 directional light; tonemap / fxaa / accumulate: those passes alone)')
+out.append(f'{"case":12s} {"kernel":62s} {"calls":>6s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s}')
+for f in sorted(glob.glob(f'{O}/case_*/**/*kernel_stats.csv', recursive=True)):
+    case = f.split('/case_')[1].split('/')[0]
+    for r in csv.DictReader(open(f)):
+        if 'mil::' not in r['Name'] or int(r['Calls']) < 9: continue
+        out.append(f'{case:12s} {r["Name"][:62]:62s} {r["Calls"]:>6s} {float(r["AverageNs"])/1e3:10.2f} {float(r["MinNs"])/1e3:10.2f} {float(r["MaxNs"])/1e3:10.2f}')
 # --- PMC
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f'{O}/pmc_*/**/*counter_collection.csv', recursive=True):

@@ -17,8 +17,14 @@ for k in headline dual l4096 k1; do
   timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $O/pmc_${k}_SQ -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_SQ.log 2>&1
   timeout -s KILL 120 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_${k}_GRBM -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_GRBM.log 2>&1
 done
+# per-workload kernel times: bench.py runs many workloads in one process and k_tiled / k_shade serve several of them, so its
+# kernel_stats cannot be read per workload; every run_case case alone under --kernel-trace --stats
+for k in headline dual l4096 k1 tonemap fxaa accumulate; do
+  NPT=256; [ $k = l4096 ] && NPT=4096
+  NPT=$NPT timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $O/case_$k -- python3 tools/run_case.py $k 12 > $O/case_$k.log 2>&1
+done
 find $O -name '*.db' -delete
 python3 tools/prof_summary.py $O $R
 # keep only the condensed artefacts (gpurun copies back at most 64 MiB)
 for f in $(find $O/stats -name '*kernel_stats.csv'); do cp $f $O/kernel_stats_$R.csv; done
-rm -rf $O/stats $O/pmc_*/ $O/*.log
+rm -rf $O/stats $O/pmc_*/ $O/case_*/ $O/*.log
