@@ -435,6 +435,10 @@ int mil_mg_render_frames(mil_mg *mg, const mil_mg_rank_io *io, const mil_frame_m
                          const mil_directional_light *lights, const mil_push_constants *push, mil_out_format fmt,
                          uint32_t flags, void *const *slots, uint32_t slot_pitch_px);
 int mil_mg_sync(mil_mg *mg);          /* waits for every local rank's compute and gather stream; reports async RCCL errors */
+/* Test hook, NO COUNTERPART IN THE REFERENCE: idles rank 0's gather stream for `microseconds` (<= 100 000) at the point where
+ * it is called, so that a test can hold the scatter of one frame back while the next frame is already being shaded and sent
+ * (the ordering of the staging slices).  Does nothing in a process that does not drive rank 0. */
+int mil_mg_debug_delay_gather(mil_mg *mg, uint32_t microseconds);
 
 int mil_sync(mil_ctx *ctx, void *stream);
 int mil_last_hip_error(const mil_ctx *ctx);

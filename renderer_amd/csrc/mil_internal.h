@@ -112,6 +112,9 @@ int shade(mil_ctx *c, const mil_gbuffer *gb, const mil_frame_matrix_data *frame,
           uint32_t out_pitch_px, mil_out_format fmt, uint32_t flags, void *stream, const mil_band_layout *bands,
           bool out_frame, const PreStaged *pre);
 
+// mil_noalloc.hip (the one HIP translation unit of the host layer): a kernel that idles a stream for a while (test hook)
+hipError_t launch_delay(hipStream_t s, uint32_t microseconds);
+
 // mil_noalloc.hip: per context at mil_create, with its device current: hipGetSymbolAddress of the static scratch array
 int noalloc_init(mil_ctx *c);
 

@@ -52,7 +52,22 @@ __global__ __launch_bounds__(256) void k_prepare_lights(const DirBlock dirs, uin
     }
 }
 
+// Test hook of the multi-GPU layer (mil_mg_debug_delay_gather): one wave that sleeps until `ticks` of the 100 MHz counter
+// have passed - an exit condition it reaches by itself; the host caps the time at 100 ms.
+__global__ __launch_bounds__(64) void k_delay(unsigned long long ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 } // namespace
+
+hipError_t milhost::launch_delay(hipStream_t s, uint32_t microseconds)
+{
+    unsigned long long ticks = 100ull * (microseconds > 100000u ? 100000u : microseconds);
+    void *args[] = { (void *)&ticks };
+    return hipLaunchKernel((const void *)k_delay, dim3(1), dim3(64), args, 0, s);
+}
 
 // mil_create, once per context, with the context's device current: each GPU holds its own copy of the array at its own
 // address.

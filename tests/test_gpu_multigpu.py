@@ -163,3 +163,36 @@ def test_frames_in_flight_rotating_and_reused_buffers():
     finally:
         mg.close()
         lp.close()
+
+
+def test_staging_slices_survive_a_held_back_scatter():
+    """dealt bands of ranks 1.. travel into staging slices on rank 0's device and are scattered into the frame
+    from there; with the peer-copy transport the copies INTO the slices run on the senders' streams, and nothing used to
+    order frame i + 1's copies behind frame i's scatter - only timing hid it.  Here the scatter of every frame is held back
+    (mil_mg_debug_delay_gather idles rank 0's gather stream in front of it) while the next frame, with different lights, is
+    already shaded and sent: every assembled frame must still be its own.  (Checked against the unfixed build: with two
+    ranks it FAILS there - frame k shows frame k + 1's rows; with four ranks the eight streams share the box's four hardware
+    queues and the held-back queue happens to hold the senders back too, which is what had hidden the race.)"""
+    w, h, n = 512, 288, 2          # two ranks = four streams: one hardware queue each (GPU_MAX_HW_QUEUES is 4), nothing serialises them by accident
+    gb, frame, dl, _, sh = scene(w, h, 0, 128)
+    lights = [synth.point_light_field(600, 0x5EED0200 + k) for k in range(5)]
+    lp = lighting.LightingPass(0, 4096)
+    want = [lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_SRGB8) for pl in lights]
+    assert not torch.equal(want[0], want[1])
+    mg = multigpu.MultiGpu.single_process([0] * n, max_point_lights=4096, band_rows=16, chunks=1, transport=multigpu.TRANSPORT_PEER_COPY)
+    try:
+        mg.reserve(w, h, lighting.OUT_SRGB8)
+        rows = [torch.from_numpy(multigpu.frame_rows_of_rank(h, n, r, band_rows=16)).to(DEV) for r in range(n)]
+        parts_gb = [{k: (v[rows[r]].contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()} for r in range(n)]
+        outs = [[None if r == 0 else torch.zeros((len(rows[r]), w), dtype=torch.int32, device=DEV) for r in range(n)] for _ in lights]
+        fulls = [torch.zeros((h, w), dtype=torch.int32, device=DEV) for _ in lights]
+        for k, pl in enumerate(lights):
+            mg.debug_delay_gather(3000)            # 3 ms in front of frame k's receives and scatter; shading a frame takes ~0.1 ms
+            parts = [dict(gb=parts_gb[r], point_lights=pl, ambient=AMB, shadow=sh, out=outs[k][r]) for r in range(n)]
+            mg.render_strips(parts, frame, dl, w, h, fmt=lighting.OUT_SRGB8, full=fulls[k])
+        mg.sync()
+        for k in range(len(lights)):
+            assert torch.equal(fulls[k], want[k]), k
+    finally:
+        mg.close()
+        lp.close()
