@@ -206,6 +206,32 @@ def test_headline_4k_bare_tolerance_census(lp, coracle):
     assert (np.abs(got8 - ref8).max(-1) > 1).mean() <= 2e-4
 
 
+def test_noise_1080p_fast_census(lp, coracle):
+    """Scene B at 1920x1080 (every plane i.i.d. noise - every roughness byte incl. 0, i.e. alpha = 1e-8, normals and
+    depths unrelated: the worst case for D_GGX's conditioning): the fast path against the float64 oracle on all 2 M pixels.
+    Measured in round 3: 0 pixels outside the bare 1e-3 + 1e-4 |b| with the two directional lights alone (the reference-order
+    FP32 evaluation: 100), 5 with 64 point lights added (190), 1 of them the fast path's own; none outside bar + conditioning
+    term, nothing non-finite."""
+    w, h = 1920, 1080
+    cam = synth.sweep_camera(w, h)
+    gb = synth.scene_noise(w, h, 0x5EED0001, device=DEV)
+    planes = planes_np(gb)
+    frame, dl = cam.frame_matrix_data(), ubo.default_directional_lights()
+    for n_point, ceiling in ((0, 4), (64, 24)):
+        pl = synth.point_light_field(n_point, 5) if n_point else None
+        r64, cond = coracle.shade_f64(*planes, frame, dl, point_lights=pl, ambient=AMB, want_cond=True)
+        ref32 = coracle.shade(*planes, frame, dl, point_lights=pl, ambient=AMB)
+        fast = lp.light_ex(gb, frame, dl, pl, AMB, None).cpu().numpy()
+        assert np.isfinite(fast).all() and np.all(fast[..., 3] == 1.0)
+        fin = np.isfinite(r64[..., :3]).all(-1) & np.isfinite(ref32[..., :3]).all(-1)      # the literal shader is NaN at L = -V exactly
+        bare, with_cond, own, emax = hdr_census(fast, r64, cond, ref32)
+        ref_bare = (np.abs(ref32[..., :3].astype(np.float64) - r64[..., :3]) > 1e-3 + 1e-4 * np.abs(r64[..., :3])).any(-1)
+        print(f'noise 1080p, {n_point} point lights: fast outside the bare bar {int((bare & fin).sum())} (reference-order FP32: {int((ref_bare & fin).sum())}), '
+              f'own {int((own & fin).sum())}, with the conditioning term {int((with_cond & fin).sum())}')
+        assert (bare & fin).sum() <= ceiling and (with_cond & fin).sum() == 0 and (own & fin).sum() <= 4
+        assert (bare & fin).sum() <= (ref_bare & fin).sum()
+
+
 @pytest.mark.parametrize('strict', [False, True])
 def test_dealt_bands_equal_monolithic(lp, strict):
     """mil_shade_bands: the frame's bands dealt cyclically over n ranks (each rank emulated on this one GPU), every
