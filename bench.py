@@ -547,29 +547,67 @@ def emit(res, saved_stdout):
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks as CHILD processes of this one - which has made no
     GPU call and imports nothing that does - with the driver's own command line, relay rank 0's one JSON line, return the
-    launcher's exit code.  No exec: the parent stays and only waits."""
+    launcher's exit code.  No exec: the parent stays and only waits.  The ranks get MIL_BENCH_TIMEOUT seconds (default 1500);
+    at the limit their process group is killed and nothing else is started.  If the ranks of the default path (mil_mg: RCCL
+    inside libmil.so) END with an error that is not "no GPU", the same command runs once more over the Python gather
+    (--gather torch) and its line says so (`fallback`): a scaling line over the older path beats none."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as so:          # a free rendezvous port on the loopback address
-        so.bind(('127.0.0.1', 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    print(f'bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks as child processes: {" ".join(cmd)}', file=sys.stderr, flush=True)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), MIL_BENCH_CHILD='1')
-    child = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
-    line = None
-    for ln in child.stdout.decode(errors='replace').splitlines():
+    import threading
+
+    def run_ranks(extra):
+        with socket.socket() as so:          # a free rendezvous port on the loopback address
+            so.bind(('127.0.0.1', 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        print(f'bench.py: --gpus {args.gpus} without a launcher: starting {args.gpus} ranks as child processes: {" ".join(cmd)}', file=sys.stderr, flush=True)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), MIL_BENCH_CHILD='1')
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, start_new_session=True)
+        seen = dict(no_device=False)
+
+        def relay():                         # the ranks' stderr goes through line by line (progress stays visible)
+            for raw in child.stderr:
+                ln = raw.decode(errors='replace')
+                seen['no_device'] |= 'MIL_ERR_NO_DEVICE' in ln
+                sys.stderr.write(ln)
+                sys.stderr.flush()
+        th = threading.Thread(target=relay, daemon=True)
+        th.start()
+        timed_out = False
         try:
-            if 'metric' in json.loads(ln):
-                line = ln
-        except ValueError:
-            print(ln, file=sys.stderr)          # anything else a rank wrote to stdout
-    if child.returncode == 0 and line is not None:
+            out, _ = child.communicate(timeout=float(os.environ.get('MIL_BENCH_TIMEOUT', '1500')))
+        except subprocess.TimeoutExpired:
+            timed_out = True
+            os.killpg(child.pid, signal.SIGKILL)     # exactly the group started above
+            out, _ = child.communicate()
+        th.join(timeout=5)
+        line = None
+        for ln in out.decode(errors='replace').splitlines():
+            try:
+                if 'metric' in json.loads(ln):
+                    line = ln
+            except ValueError:
+                print(ln, file=sys.stderr)          # anything else a rank wrote to stdout
+        return child.returncode, line, timed_out, seen['no_device']
+
+    rc, line, timed_out, no_device = run_ranks([])
+    if rc == 0 and line is not None:
         print(line, flush=True)
         return 0
-    print(f'bench.py: the {args.gpus}-rank run failed (launcher exit code {child.returncode}' + ('' if line else ', no result line') + ')', file=sys.stderr)
-    return child.returncode or 1
+    why = 'time limit' if timed_out else f'launcher exit code {rc}' + ('' if line else ', no result line')
+    print(f'bench.py: the {args.gpus}-rank run failed ({why})', file=sys.stderr)
+    if timed_out or no_device or args.gather != 'mil_mg' or os.environ.get('MIL_BENCH_NO_FALLBACK') == '1':
+        return rc or 1
+    print('bench.py: once more over the Python gather (--gather torch)', file=sys.stderr)
+    rc2, line2, _, _ = run_ranks(['--gather', 'torch'])
+    if rc2 == 0 and line2 is not None:
+        res = json.loads(line2)
+        res['fallback'] = f'the mil_mg (RCCL inside libmil.so) run of this command failed ({why}); this line is the --gather torch path'
+        print(json.dumps(res), flush=True)
+        return 0
+    return rc2 or rc or 1
 
 
 def main():
@@ -589,6 +627,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
         args.gpus = world
+    if os.environ.get('MIL_BENCH_FAIL_MG') == '1' and world > 1 and args.gather == 'mil_mg':
+        sys.exit(3)                          # test hook (tests/test_host_logic.py): the mil_mg ranks end with an error
     n_dev = torch.cuda.device_count()       # counting devices does not initialise the GPU
     rehearse_env = os.environ.get('MIL_BENCH_REHEARSE') == '1'
     if n_dev == 0 or (local_rank >= n_dev and not rehearse_env):

@@ -91,3 +91,24 @@ def test_bench_gpus_n_starts_its_own_ranks_and_fails_cleanly_without_a_gpu():
     assert r.stdout.strip() == b''
     assert 'starting 2 ranks as child processes' in err and 'torch.distributed.run' in err
     assert 'MIL_ERR_NO_DEVICE' in err
+
+
+def test_bench_self_launch_falls_back_to_the_python_gather_once():
+    """A mil_mg run whose ranks END with an error (forced here: MIL_BENCH_FAIL_MG) is followed by ONE run over --gather torch;
+    without a GPU that one ends with MIL_ERR_NO_DEVICE, which is final (no third run, no line)."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('needs a machine with fewer than two GPUs')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MIL_BENCH_REHEARSE')}
+    env['MIL_BENCH_FAIL_MG'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu'],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    err = r.stderr.decode(errors='replace')
+    assert r.returncode != 0 and r.stdout.strip() == b''
+    assert err.count('starting 2 ranks as child processes') == 2
+    assert 'once more over the Python gather' in err and '--gather torch' in err
+    assert 'MIL_ERR_NO_DEVICE' in err
