@@ -1024,6 +1024,7 @@ template <int CTRL> DEV float dpp_f(float v)
 template <int CTRL> DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 // 0xB1 quad_perm[1,0,3,2], 0x4E quad_perm[2,3,0,1], 0x141 row_half_mirror, 0x140 row_mirror:
 // after the four steps every lane holds its 16-lane row's result; rows are combined by readlane.
+DEV float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 DEV float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 DEV float wave_min(float v)
 {
@@ -1111,6 +1112,27 @@ DEV v4f bcast4(v4f v, int k)
     return v4f{ lane_f(v.x, k), lane_f(v.y, k), lane_f(v.z, k), lane_f(v.w, k) };
 }
 
+#if !MIL_STRICT
+// A point light's 32-byte record through the SCALAR cache, issued by hand.  The fast kernels walk a tile's light list one
+// light at a time with the record in SGPRs (wave-uniform operands of the packed arithmetic).  Broadcasting it out of a
+// lane's VGPRs cost 8 v_readlane per light (a third of a rejected light's instructions); a compiler-scheduled scalar load
+// is sunk to its first use and exposes the whole scalar-cache latency per light.  srec_load issues s_load_dwordx8 by inline
+// asm - the compiler does not know the destination is still in flight - and srec_wait (s_waitcnt lgkmcnt(0)) comes before
+// the source touches it and before a loop's back edge.  That the COMPILER does not touch it in between either (copy, spill)
+// is proved on the assembly by tools/check_srec.py (tests/test_abi.py runs it).  Loads only: nothing is written through
+// the scalar cache.  Same records, same arithmetic, same bits as the broadcast form.
+typedef float f8v __attribute__((ext_vector_type(8)));
+struct SRec { f8v f; };
+DEV SRec srec_load(uint64_t base, uint32_t li)
+{
+    SRec r;
+    const uint64_t addr = base + (uint64_t)li * 32u;
+    asm volatile("s_load_dwordx8 %0, %1, 0x0 ; SREC_LOAD" : "=s"(r.f) : "s"(addr));
+    return r;
+}
+DEV void srec_wait() { asm volatile("s_waitcnt lgkmcnt(0) ; SREC_WAIT" ::: "memory"); }
+#endif
+
 // The kernel-argument block again, through a pointer the optimiser cannot see through: uniforms read
 // through it are re-fetched from the scalar cache in the phase that uses them instead of being held in
 // SGPRs across the whole kernel (which spills them into VGPR lanes).
@@ -1122,8 +1144,11 @@ DEV const ShadeParams &kernarg_params()
     return *(const ShadeParams *)pp;
 }
 
-template <int FMT, bool FRAME>
-__global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
+// STAGE: the LDS-staged PCF taps (MIL_FLAG_SHADOW_LDS) as an instantiation of their own - the rectangle bookkeeping they
+// keep live across the passes would otherwise cost every launch its registers.  Without it a wave needs <= 96 VGPRs (or
+// spills three dwords per lane, hdr output), which admits five waves per SIMD instead of four (measured -1 ... -3.5 %).
+template <int FMT, bool FRAME, bool STAGE>
+__global__ __launch_bounds__(256, STAGE ? 4 : 5) void k_tiled(const ShadeParams p_arg)
 {
     const ShadeParams &p = kernarg_params();
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -1144,7 +1169,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                  "s"(k_width), "s"(k_height), "s"(k_pitch), "s"(k_resolve_dma), "s"(k_has_sky), "s"(k_albedo), "s"(k_accum), "s"(k_stamps),
                  "s"(k_y_offset), "s"(k_band_shift), "s"(k_band_extra), "s"(k_out_band_extra));
     const bool do_shadow = k_has_shadow && k_n_dir > 0;
-    const bool stage = do_shadow && k_shadow_lds;
+    const bool stage = STAGE && do_shadow && k_shadow_lds;
     // whole frame with a resolve: the tile's accum / revealage texels ride the LDS-DMA with the G-buffer planes, so their
     // latency is not exposed at the store (dword granularity: the host sets resolve_dma when pitches / width allow it)
     const bool rdma = FRAME && k_accum && k_resolve_dma;
@@ -1312,6 +1337,9 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         wave_aabb(lo, hi);
         any_lit = lo.x <= hi.x;
     }
+    // the reduced box is wave-uniform: held in SGPRs for the culling trips (as VGPRs it was six registers live across the
+    // rounds loop, one of them spilled under the five-wave budget)
+    const f3 blo = { uniform_f(lo.x), uniform_f(lo.y), uniform_f(lo.z) }, bhi = { uniform_f(hi.x), uniform_f(hi.y), uniform_f(hi.z) };
     bool staged = false;
     int rx0 = 0, ry0 = 0, rw = 0;
     if (stage) {
@@ -1359,7 +1387,7 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {          // straight-line: rejected lanes write the dump entry behind the list
                     const uint32_t li = b0 + 64 * u + lane;
-                    const bool pass = (li < end) & (box_d2(c4[u], lo, hi) < c4[u].w * c4[u].w);
+                    const bool pass = (li < end) & (box_d2(c4[u], blo, bhi) < c4[u].w * c4[u].w);
                     const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
                     const uint32_t pos = cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     s_list[pass ? pos : list_cap] = (uint16_t)li;
@@ -1374,13 +1402,15 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
         last = next >= end;
         total += cnt;
 
-        // ---- 5. lane k <- record of list entry kb + k ----
+        // ---- 5. strict mode: lane k <- record of list entry kb + k, broadcast by v_readlane in the passes (fast mode: srec_load) ----
+#if MIL_STRICT
         auto gather = [&](uint32_t kb, v4f &ga, v4f &gb) {
             const uint32_t li = s_list[min(kb + lane, cnt - 1)];
             ga = point_rec_a_v(p, li); gb = point_rec_b_v(p, li);
         };
         v4f ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
         if (cnt) gather(0, ra, rb);       // stays in registers across the passes unless the list is longer than 64
+#endif
 
         // E3 shadow term of one pixel (integer logic shared by both numeric modes)
         auto shadow_px = [&](const ShadowTap &st) -> float {
@@ -1466,8 +1496,12 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
             Px2 q;
             PosT<v2f> pos;
             if (have_pos) {       // the box phase evaluated this (same function, same inputs): read it back
+                // (the lane's address is formed here, per pass: hoisted out of the rounds loop it was held in a VGPR across
+                // the whole kernel and spilled to scratch memory under the five-wave register budget)
+                uint32_t ln = lane;
+                asm volatile("" : "+v"(ln));
                 const v2f *park = (const v2f *)(s_wave + L.pos) + jp * 192;
-                pos.D = V3<v2f>{ park[lane], park[64 + lane], park[128 + lane] };
+                pos.D = V3<v2f>{ park[ln], park[64 + ln], park[128 + ln] };
                 pos.P = V3<v2f>{ pos.D.x + p.cam[0], pos.D.y + p.cam[1], pos.D.z + p.cam[2] };
             } else {
                 pos = pixel_position_t<v2f>(p, (v2f)((float)x), v2f{ (float)(ya + rm.g), (float)(yb + rm.g) }, depth);
@@ -1493,25 +1527,35 @@ __global__ __launch_bounds__(256, 4) void k_tiled(const ShadeParams p_arg)
                 r.z = v2f{ s_res[512 + ja * 64 + lane], s_res[512 + (ja + 1) * 64 + lane] };
             }
             if (cnt) {
+                auto light = [&](const SRec &rec) {
+                    const v4f a = { rec.f[0], rec.f[1], rec.f[2], rec.f[3] };
+                    V3<v2f> Lv;
+                    const v2f d2 = point_d2_2(q, a, Lv);
+                    const PointMasks pm = point_masks(d2, a.w);
+                    if ((pm.m0 | pm.m1) == 0) return;         // wave-uniform: nobody in range
+                    const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
+                    point_eval2(q, v4f{ rec.f[4], rec.f[5], rec.f[6], rec.f[7] }, Lv, d2, on0, on1, r);
+                };
+                const uint64_t recs = (uint64_t)(uintptr_t)p.point_prep;
                 uint32_t kb = 0;
 #pragma unroll 1
                 for (;;) {
                     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, cnt - kb));      // scalar loop bound
+                    const uint32_t lv = s_list[min(kb + lane, cnt - 1)];
+                    SRec r0 = srec_load(recs, (uint32_t)__builtin_amdgcn_readlane((int)lv, 0)), r1;
+                    srec_wait();
 #pragma unroll 1
-                    for (uint32_t k = 0; k < n; k++) {
-                        const v4f a = bcast4(ra, (int)k);
-                        V3<v2f> Lv;
-                        const v2f d2 = point_d2_2(q, a, Lv);
-                        const PointMasks pm = point_masks(d2, a.w);
-                        if ((pm.m0 | pm.m1) == 0) continue;   // wave-uniform: nobody in range
-                        const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
-                        point_eval2(q, bcast4(rb, (int)k), Lv, d2, on0, on1, r);
+                    for (uint32_t k = 0; k < n; k += 2) {
+                        r1 = srec_load(recs, (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)min(k + 1u, n - 1u)));
+                        light(r0);
+                        srec_wait();
+                        r0 = srec_load(recs, (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)min(k + 2u, n - 1u)));
+                        if (k + 1u < n) light(r1);
+                        srec_wait();
                     }
                     kb += 64;
                     if (kb >= cnt) break;
-                    gather(kb, ra, rb);
                 }
-                if (cnt > 64 && jp == 0) gather(0, ra, rb);
             }
             if (last) {
                 if (!FRAME) emit_pair<FMT>(p, x, ya, yb, rm, inA, inB, r);
@@ -1866,16 +1910,10 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
     const v2u u1 = { __builtin_nontemporal_load(p.normal + ia), __builtin_nontemporal_load(p.normal + ib) };
     const v2u u3 = { __builtin_nontemporal_load(p.rm + ia), __builtin_nontemporal_load(p.rm + ib) };
     const v2f depth = { __builtin_nontemporal_load(p.depth + ia), __builtin_nontemporal_load(p.depth + ib) };
-    // the list's first block of records, requested with the texels
     const bool brute = (meta & MIL_WS_BRUTE) != 0;
     const uint32_t len = brute ? 0u : (meta & 0xFFFFu);
     const uint16_t *const list = p.ws_pool + list_off;
-    auto gather = [&](uint32_t kb, v4f &ga, v4f &gb) {
-        const uint32_t li = list[min(kb + lane, len - 1)];
-        ga = point_rec_a_v(p, li); gb = point_rec_b_v(p, li);
-    };
-    v4f ra = { 0.0f, 0.0f, 0.0f, 0.0f }, rb = ra;
-    if (len) gather(0, ra, rb);
+    uint32_t lv = len ? list[min(lane, len - 1u)] : 0u;      // lane k: index of list entry k, requested with the texels
     const RowMap rm = row_map(p, tyi * TILE);
     const bool inA = x < p.width && ya <= ylast, inB = x < p.width && yb <= ylast;
     const bool litA = inA && (w2.x >> 24) != 0, litB = inB && (w2.y >> 24) != 0;
@@ -1899,25 +1937,41 @@ __global__ __launch_bounds__(256, MIL_SHADE_WAVES) void k_shade(const ShadeParam
     far_if_unlit(q);                                         // after the taps (they read P), before the loops (occlusion dies here)
     for (uint32_t l = 0; l < p.n_dir; l++) add_directional2(q, dir_rec(p, l), shadow, do_shadow && l == 0, r);   // fs_deferred_lighting.glsl:62-64
     if (len) {
+        // Records through the scalar cache: lane k holds the index of list entry kb + k; one v_readlane brings an index to an
+        // SGPR and one s_load_dwordx8 fetches its record WHILE the light before it is evaluated (no VALU broadcasts).  The
+        // compiler sinks a scalar load to its first use, so the load is issued by hand (srec_load) and waited for by hand
+        // (srec_wait) - always before the record is touched and before the loop's back edge.
+        auto light = [&](const SRec &rec) {
+            const v4f a = { rec.f[0], rec.f[1], rec.f[2], rec.f[3] };
+            V3<v2f> Lv;
+            const v2f d2 = point_d2_2(q, a, Lv);
+            const PointMasks pm = point_masks(d2, a.w);
+            if ((pm.m0 | pm.m1) == 0) return;             // wave-uniform: nobody in range
+            const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
+            point_eval2(q, v4f{ rec.f[4], rec.f[5], rec.f[6], rec.f[7] }, Lv, d2, on0, on1, r);
+        };
+        const uint64_t recs = (uint64_t)(uintptr_t)p.point_prep;
         uint32_t kb = 0;
 #pragma unroll 1
         for (;;) {
             const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min(64u, len - kb));      // scalar loop bound
+            SRec r0 = srec_load(recs, (uint32_t)__builtin_amdgcn_readlane((int)lv, 0)), r1;
+            srec_wait();
 #pragma unroll 1
-            for (uint32_t k = 0; k < n; k++) {
-                const v4f a = bcast4(ra, (int)k);
-                V3<v2f> Lv;
-                const v2f d2 = point_d2_2(q, a, Lv);
-                const PointMasks pm = point_masks(d2, a.w);
-                if ((pm.m0 | pm.m1) == 0) continue;       // wave-uniform: nobody in range
-                const bool on0 = __builtin_amdgcn_inverse_ballot_w64(pm.m0), on1 = __builtin_amdgcn_inverse_ballot_w64(pm.m1);
-                point_eval2(q, bcast4(rb, (int)k), Lv, d2, on0, on1, r);
+            for (uint32_t k = 0; k < n; k += 2) {
+                r1 = srec_load(recs, (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)min(k + 1u, n - 1u)));
+                light(r0);
+                srec_wait();
+                r0 = srec_load(recs, (uint32_t)__builtin_amdgcn_readlane((int)lv, (int)min(k + 2u, n - 1u)));
+                if (k + 1u < n) light(r1);
+                srec_wait();
             }
             kb += 64;
             if (kb >= len) break;
-            gather(kb, ra, rb);
+            lv = list[min(kb + lane, len - 1u)];
         }
-    } else if (brute) {                                   // every light, as the brute-force kernel (same order, same bits)
+    } else if (brute) {
+                                   // every light, as the brute-force kernel (same order, same bits)
 #pragma unroll 1
         for (uint32_t l = 0; l < p.n_point; l++) {
             const v4f a = point_rec_a(p, l);
@@ -2347,9 +2401,10 @@ hipError_t launch_tiled(int fmt, const ShadeParams &p, bool frame, hipStream_t s
     const uint32_t wpb = (p.tune & 2u) ? 1 : ((p.tune & 4u) ? 2 : 4);
     dim3 block(64 * wpb), grid(((p.tiles_x + wpb - 1) / wpb) * p.tiles_y);
     const size_t lds = (size_t)wpb * tiled_lds(p.n_point, p.has_shadow && p.shadow_lds && p.n_dir, frame && p.accum && p.resolve_dma).per_wave;
+    const bool stage = p.has_shadow && p.shadow_lds && p.n_dir;
 #define MIL_LAUNCH_TILED(F)                                                             \
-    if (frame) return launch_k(k_tiled<F, true>, grid, block, lds, s, p);            \
-    else return launch_k(k_tiled<F, false>, grid, block, lds, s, p);
+    if (frame) return stage ? launch_k(k_tiled<F, true, true>, grid, block, lds, s, p) : launch_k(k_tiled<F, true, false>, grid, block, lds, s, p);   \
+    else return stage ? launch_k(k_tiled<F, false, true>, grid, block, lds, s, p) : launch_k(k_tiled<F, false, false>, grid, block, lds, s, p);
     switch (fmt) {
     case FMT_HDR: MIL_LAUNCH_TILED(FMT_HDR); break;
     case FMT_LDR: MIL_LAUNCH_TILED(FMT_LDR); break;

@@ -82,3 +82,22 @@ def test_product_does_not_import_the_oracle():
         for fn in files:
             if fn.endswith(('.py', '.cpp', '.hpp', '.hip', '.h')) or fn == 'Makefile':
                 assert not pat.search(open(os.path.join(dirpath, fn)).read()), fn
+
+
+def test_hand_issued_scalar_loads_are_not_touched_before_their_wait():
+    """The fast kernels fetch point-light records with s_load_dwordx8 issued by inline asm (mil_device.hpp srec_load) and wait
+    for them by hand; the compiler does not know the destination SGPRs are in flight.  tools/check_srec.py compiles
+    mil_fast.hip to assembly with the library's flags and proves, by data-flow over each kernel's control-flow graph, that no
+    instruction names such a register between the load and the wait (a copy or a spill there would read stale data)."""
+    import shutil
+    import sys
+    if not os.path.exists('/opt/rocm/bin/hipcc'):
+        pytest.skip('hipcc not present')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_srec
+    path = check_srec.listing()
+    try:
+        total, bad = check_srec.main(path)
+    finally:
+        shutil.rmtree(os.path.dirname(path), ignore_errors=True)
+    assert total >= 16 * 3 and bad == 0
