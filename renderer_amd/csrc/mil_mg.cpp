@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>
 #include <new>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -67,8 +68,16 @@ struct Piece { uint32_t local0, rows, frame0; };
 
 struct Local {                      // one rank this process drives
     int rank = 0, device = 0;
-    mil_ctx *ctx = nullptr;
-    hipStream_t compute = nullptr, gather = nullptr;
+    // Two shading lanes (context + stream), taken in turn frame by frame: a launch spends its last ~12 us below half
+    // occupancy (the heavy tiles' tail) and its first few filling the chip, so with consecutive frames on alternating streams
+    // the ramp of one runs under the tail of the other (one GPU, 4K: 256 lights 86 -> 72 us per frame, 4096 lights 424 -> 390).
+    // A context per lane because a context's workspace and light staging serve one launch at a time.  MIL_MG_LANES=1 in
+    // the environment keeps every frame on the first lane.
+    static constexpr int LANES = 2;
+    mil_ctx *ctx[LANES] = {};
+    hipStream_t compute[LANES] = {}, gather = nullptr;
+    int lanes = LANES;
+    uint64_t frames = 0;
     ncclComm_t comm = nullptr;
     std::vector<hipEvent_t> chunk_done;      // compute -> gather, one per chunk
     // The last FRAMES_IN_FLIGHT frames of this rank: an event on the gather stream behind the frame's last transfer, and the
@@ -167,14 +176,19 @@ size_t bytes_per_px(mil_out_format fmt) { return fmt == MIL_OUT_HDR_RGBA32F ? 16
 int create_common(mil_mg *m, const mil_mg_config *cfg)
 {
     for (Local &l : m->locals) {
-        int rc = mil_create(&l.ctx, l.device, cfg->max_point_lights);
-        if (rc) return rc;
+        const char *env = getenv("MIL_MG_LANES");
+        l.lanes = (env && atoi(env) == 1) ? 1 : Local::LANES;
+        for (int k = 0; k < l.lanes; k++) {
+            const int rc = mil_create(&l.ctx[k], l.device, cfg->max_point_lights);
+            if (rc) return rc;
+        }
         MG_HIP(m, hipSetDevice(l.device));
-        // One compute stream per rank.  (Measured, 8K / 4096 lights, one eighth of the frame: 405 us as one launch, 553 as two
-        // launches on one stream - the tail of the heavy tiles is paid per launch - and 461 with the first chunk on a
-        // higher-priority stream beside the second; but with 8 ranks x 3 streams on the 4 hardware queues of this pool
-        // (GPU_MAX_HW_QUEUES) mixed-priority streams stopped making progress, so every chunk runs on the one stream.)
-        MG_HIP(m, hipStreamCreateWithFlags(&l.compute, hipStreamNonBlocking));
+        // One compute stream per lane; a frame's chunks all run on its lane's stream.  (Measured, 8K / 4096 lights, one eighth
+        // of the frame: 405 us as one launch, 553 as two launches on one stream - the tail of the heavy tiles is paid per
+        // launch - and 461 with the first chunk on a higher-priority stream beside the second; but with 8 ranks x 3 streams on
+        // the 4 hardware queues of this pool (GPU_MAX_HW_QUEUES) mixed-priority streams stopped making progress: all streams
+        // here have the default priority.)
+        for (int k = 0; k < l.lanes; k++) MG_HIP(m, hipStreamCreateWithFlags(&l.compute[k], hipStreamNonBlocking));
         MG_HIP(m, hipStreamCreateWithFlags(&l.gather, hipStreamNonBlocking));
         for (hipEvent_t &e : l.gathered) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const uint32_t n = cfg->chunks ? cfg->chunks : 4u;
@@ -289,7 +303,7 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
             bool hit = k == slot;                                    // the slot about to be reused: its frame must be done
             for (const void *a : mine) for (const void *b : l.touched[k]) hit = hit || a == b;
             if (hit) {
-                MG_HIP(m, hipStreamWaitEvent(l.compute, l.gathered[k], 0));
+                MG_HIP(m, hipStreamWaitEvent(l.compute[l.frames % l.lanes], l.gathered[k], 0));
                 if (l.rank == 0) MG_HIP(m, hipStreamWaitEvent(l.gather, l.gathered[k], 0));
             }
         }
@@ -310,18 +324,19 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
             const mil_frame_matrix_data *f = per_rank_frame ? &frames[i] : frames;
             const uint32_t out_pitch = in_place[i] ? dst_pitch_px : r.out_pitch_px;
             int rc;
-            hipStream_t cs = l.compute;
+            const int lane = (int)(l.frames % l.lanes);
+            hipStream_t cs = l.compute[lane];
             if (strips && m->cfg.band_rows) {
                 const mil_band_layout b = { m->cfg.band_rows, (uint32_t)m->world, (uint32_t)l.rank, k0 / m->cfg.band_rows };
                 gb.y_offset = 0;
                 void *out = in_place[i] ? dst_of[0] : (void *)((uint8_t *)r.out + (size_t)k0 * out_pitch * bpp);
-                rc = shade(l.ctx, &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, cs, &b, in_place[i], nullptr);
+                rc = shade(l.ctx[lane], &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, cs, &b, in_place[i], nullptr);
             } else {
                 const uint32_t y0 = pl.pieces[0].frame0 + k0;      // contiguous rows: one piece
                 gb.y_offset = y0;
                 void *out = in_place[i] ? (void *)((uint8_t *)dst_of[0] + (size_t)(strips ? y0 : k0) * out_pitch * bpp)
                                         : (void *)((uint8_t *)r.out + (size_t)k0 * out_pitch * bpp);
-                rc = shade(l.ctx, &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, cs, nullptr, false, nullptr);
+                rc = shade(l.ctx[lane], &gb, f, lights, push, r.extras, nullptr, out, out_pitch, fmt, flags, cs, nullptr, false, nullptr);
             }
             if (rc) return rc;
             MG_HIP(m, hipSetDevice(l.device));
@@ -413,6 +428,7 @@ int render(mil_mg *m, const mil_mg_rank_io *io, const mil_frame_matrix_data *fra
         MG_HIP(m, hipEventRecord(l.gathered[l.frame_next], l.gather));
         l.gathered_valid[l.frame_next] = true;
         l.frame_next = (l.frame_next + 1) % Local::FRAMES_IN_FLIGHT;
+        l.frames++;
     }
     return MIL_OK;
 }
@@ -436,7 +452,7 @@ void mil_mg_destroy(mil_mg *m)
     if (!m) return;
     for (Local &l : m->locals) {
         (void)hipSetDevice(l.device);
-        if (l.compute) (void)hipStreamSynchronize(l.compute);
+        for (hipStream_t cs : l.compute) if (cs) (void)hipStreamSynchronize(cs);
         if (l.gather) (void)hipStreamSynchronize(l.gather);
     }
     for (Local &l : m->locals) {
@@ -444,9 +460,9 @@ void mil_mg_destroy(mil_mg *m)
         if (l.comm && rccl().ok) (void)rccl().CommDestroy(l.comm);
         for (hipEvent_t e : l.chunk_done) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : l.gathered) if (e) (void)hipEventDestroy(e);
-        if (l.compute) (void)hipStreamDestroy(l.compute);
+        for (hipStream_t cs : l.compute) if (cs) (void)hipStreamDestroy(cs);
         if (l.gather) (void)hipStreamDestroy(l.gather);
-        if (l.ctx) mil_destroy(l.ctx);
+        for (mil_ctx *c : l.ctx) if (c) mil_destroy(c);
     }
     if (m->stage || m->stage_free) {
         for (Local &l : m->locals) if (l.rank == 0) (void)hipSetDevice(l.device);
@@ -570,8 +586,10 @@ int mil_mg_reserve(mil_mg *m, uint32_t width, uint32_t height, mil_out_format fm
     if (!m || width == 0 || height == 0 || width > (1u << 24) || height > (1u << 24) || (unsigned)fmt > MIL_OUT_SRGB8_BGRA_VIA_LDR) return MIL_ERR_BAD_ARG;
     // every local rank's context: the two-kernel workspace for the rows it will shade (strips: its share; frames: a whole frame)
     for (Local &l : m->locals) {
-        const int rc = mil_reserve(l.ctx, width, height);
-        if (rc) return rc;
+        for (int k = 0; k < l.lanes; k++) {
+            const int rc = mil_reserve(l.ctx[k], width, height);
+            if (rc) return rc;
+        }
     }
     if (m->cfg.band_rows == 0) return MIL_OK;          // contiguous strips and whole frames are received in place
     uint32_t max_rows = 0;
@@ -598,7 +616,7 @@ int mil_mg_sync(mil_mg *m)
     if (!m) return MIL_ERR_BAD_ARG;
     for (Local &l : m->locals) {
         MG_HIP(m, hipSetDevice(l.device));
-        MG_HIP(m, hipStreamSynchronize(l.compute));
+        for (int k = 0; k < l.lanes; k++) MG_HIP(m, hipStreamSynchronize(l.compute[k]));
         MG_HIP(m, hipStreamSynchronize(l.gather));
         if (l.comm && rccl().ok) {
             ncclResult_t ae = ncclSuccess;
