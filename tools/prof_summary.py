@@ -2,9 +2,22 @@
 import collections, csv, glob, json, os, sys
 O, R = sys.argv[1], sys.argv[2]
 out = []
+# --- kernel stats of the timed step alone (bench.py --no-extra)
+for f in glob.glob(f'{O}/stats_step/**/*kernel_stats.csv', recursive=True):
+    out.append(f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu --no-extra   (the default step only: every launch is the headline workload)')
+    out.append(f'{"kernel":70s} {"calls":>6s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s} {"pct":>6s}')
+    for r in csv.DictReader(open(f)):
+        if 'mil::' not in r['Name']: continue
+        out.append(f'{r["Name"][:70]:70s} {r["Calls"]:>6s} {float(r["AverageNs"])/1e3:10.2f} {float(r["MinNs"])/1e3:10.2f} {float(r["MaxNs"])/1e3:10.2f} {float(r["Percentage"]):6.2f}')
+    try:
+        b = json.loads(open(f'{O}/bench_step_under_rocprof.json').read().strip().splitlines()[-1])
+        out.append(f'bench.py line of that run: ms_per_step {b["ms_per_step"]}, roofline.ms {b["roofline"]["ms"]} ({b["roofline"]["kernel"]}), value {b["value"]} {b["unit"]}')
+    except Exception as e:
+        out.append(f'(bench line of that run not readable: {e})')
+    out.append('')
 # --- kernel stats (rocprofv3 --kernel-trace --stats)
 for f in glob.glob(f'{O}/stats/**/*kernel_stats.csv', recursive=True):
-    out.append(f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu   ({os.path.basename(f)})')
+    out.append(f'# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu   (with the side measurements: one kernel name serves several workloads and the two-frames-in-flight leg overlaps launches; {os.path.basename(f)})')
     rows = list(csv.DictReader(open(f)))
     out.append(f'{"kernel":70s} {"calls":>6s} {"avg_us":>10s} {"min_us":>10s} {"max_us":>10s} {"pct":>6s}')
     for r in rows:

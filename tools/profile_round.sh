@@ -8,6 +8,9 @@ R=${1:-r01}
 O=gpurun_out/prof_$R
 mkdir -p $O
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 30 --warmup 5 --no-cpu > $O/bench_under_rocprof.json 2> $O/stats.err
+# the same command without the side measurements: every launch of its kernel is the timed step's workload, so the kernel's
+# average here is the one bench.py's roofline leg must agree with
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_step -- python3 bench.py --steps 30 --warmup 5 --no-cpu --no-extra > $O/bench_step_under_rocprof.json 2> $O/stats_step.err
 for c in FETCH_SIZE WRITE_SIZE; do
   for k in headline dual l4096 k1 accumulate; do
     timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $O/pmc_${k}_$c -- python3 tools/run_case.py $k 9 > $O/pmc_${k}_$c.log 2>&1
@@ -27,4 +30,4 @@ find $O -name '*.db' -delete
 python3 tools/prof_summary.py $O $R
 # keep only the condensed artefacts (gpurun copies back at most 64 MiB)
 for f in $(find $O/stats -name '*kernel_stats.csv'); do cp $f $O/kernel_stats_$R.csv; done
-rm -rf $O/stats $O/pmc_*/ $O/case_*/ $O/*.log
+rm -rf $O/stats $O/stats_step $O/pmc_*/ $O/case_*/ $O/*.log
