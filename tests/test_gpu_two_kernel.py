@@ -75,6 +75,26 @@ def test_two_kernel_equals_one_kernel_and_brute_force(two, one, kind, w, h, n_po
         two2.close(); one2.close()
 
 
+@pytest.mark.parametrize('n_point', [1, 2, 3, 62, 63, 64, 65, 66, 127, 128, 129, 130, 191, 193])
+def test_list_lengths_at_the_record_loop_boundaries(two, one, n_point):
+    """The fast kernels walk a tile's list in blocks of 64 indices, two lights per turn of the loop, the next light's record
+    requested (s_load_dwordx8 issued by hand, mil_device.hpp srec_load) while the current one is evaluated.  Every light here
+    reaches every pixel, so every tile's and half tile's list holds exactly n_point entries: odd and even lengths, one below /
+    at / above a block and two blocks.  Both forms == the brute-force launch bit for bit, on a frame with ragged edges."""
+    gb, frame, dl, pl, sh = scene('sweep', 88, 52, n_point, 32, seed=0x5EED0100 + n_point)
+    pl = pl.copy()
+    pl[:, 3] = 80.0
+    pl[:, 7] = 0.02
+    brute = one.light_ex(gb, frame, dl, pl, AMB, sh, flags=lighting.FLAG_NO_CULL)
+    assert same(brute, one.light_ex(gb, frame, dl, pl, AMB, sh))
+    assert same(brute, two.light_ex(gb, frame, dl, pl, AMB, sh))
+    counts = one.tile_counts(gb)
+    one.light_ex(gb, frame, dl, pl, AMB, sh)
+    one.tile_counts(gb, enable=False)
+    lit_tiles = counts[counts > 0]
+    assert lit_tiles.numel() > 0 and int(lit_tiles.min()) == n_point and int(lit_tiles.max()) == n_point
+
+
 def test_two_kernel_lists_beyond_capacity_fall_back_to_brute_force(two, one, coracle):
     """More lights reach a half tile than a workspace list holds (1024): that half tile is shaded by the brute-force loop,
     still in ascending light order: == the one-kernel form (which takes rounds) bit for bit; strict stays == the C oracle."""
