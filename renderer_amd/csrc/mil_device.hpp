@@ -1127,7 +1127,8 @@ DEV SRec srec_load(uint64_t base, uint32_t li)
 {
     SRec r;
     const uint64_t addr = base + (uint64_t)li * 32u;
-    asm volatile("s_load_dwordx8 %0, %1, 0x0 ; SREC_LOAD" : "=s"(r.f) : "s"(addr));
+    // early clobber: the destination never overlaps the address pair (a replayed load - XNACK - would read a clobbered address)
+    asm volatile("s_load_dwordx8 %0, %1, 0x0 ; SREC_LOAD" : "=&s"(r.f) : "s"(addr));
     return r;
 }
 DEV void srec_wait() { asm volatile("s_waitcnt lgkmcnt(0) ; SREC_WAIT" ::: "memory"); }

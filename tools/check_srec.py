@@ -5,7 +5,8 @@ being written; srec_wait (`s_waitcnt lgkmcnt(0)`) comes before the source touche
 that the COMPILER leaves them alone in between (a copy, a spill into a VGPR lane): this script proves it on the assembly.
 Per kernel it builds the control-flow graph of the listing and runs a forward data-flow: SREC_LOAD adds its destination
 SGPRs to the pending set, SREC_WAIT empties it, a block starts with the union over its predecessors; an instruction that
-names a pending SGPR (read or write) is an error.
+names a pending SGPR (read or write) is an error, and so is a load whose destination overlaps its own address pair (a
+replayed load would read a clobbered address).
 
 usage: python tools/check_srec.py [listing.s]     (without an argument: compiles mil_fast.hip with -S first)"""
 import os
@@ -95,7 +96,7 @@ def check(name, body):
             if 'SREC_LOAD' in t:
                 m = re.match(r's_load_dwordx8\s+s\[(\d+):(\d+)\],\s*(\S+),', t)
                 dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
-                hit = (sregs(m.group(3)) & pend) | (dst & pend)
+                hit = (sregs(m.group(3)) & pend) | (dst & pend) | (sregs(m.group(3)) & dst)     # the last: destination over its own address
                 if hit:
                     errors.add((blocks[i]['label'], t, tuple(sorted(hit))))
                 pend |= dst
