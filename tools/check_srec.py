@@ -47,8 +47,6 @@ def kernels(path):
             continue
         if name is not None:
             body.append(ln.rstrip('\n'))
-            if re.match(r'^\s*s_endpgm', ln) and re.search(r'\.Lfunc_end|^\s*$', ''):
-                pass
             if ln.startswith('.Lfunc_end'):
                 yield name, body
                 name = None
