@@ -13,8 +13,10 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <chrono>
 #include <new>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -77,6 +79,7 @@ struct Local {                      // one rank this process drives
     mil_ctx *ctx[LANES] = {};
     hipStream_t compute[LANES] = {}, gather = nullptr;
     int lanes = LANES;
+    bool lanes_overlap = false;     // the probe at creation saw the two lane streams run side by side
     uint64_t frames = 0;
     ncclComm_t comm = nullptr;
     std::vector<hipEvent_t> chunk_done;      // compute -> gather, one per chunk
@@ -173,6 +176,39 @@ void pieces_in(const std::vector<Piece> &pieces, uint32_t k0, uint32_t k1, std::
 
 size_t bytes_per_px(mil_out_format fmt) { return fmt == MIL_OUT_HDR_RGBA32F ? 16u : 4u; }
 
+// The second lane's stream must not share a hardware queue with the first: HIP deals a process's streams over its hardware
+// queues (GPU_MAX_HW_QUEUES, 4 here) in creation order, and two streams on one queue run their kernels one after the other -
+// the lanes would then buy nothing.  Probe: a 300 us spin kernel (one wave) on the first lane and on a candidate at once; if
+// the pair takes about one spin they run side by side.  Up to three candidates, the rest are destroyed; if none overlaps the
+// last one is kept (correct either way, the order of frames rests on events).  ~1-2 ms once per rank at creation.
+int second_lane_stream(mil_mg *m, Local &l)
+{
+    const uint32_t spin_us = 300;
+    MG_HIP(m, launch_delay(l.compute[0], 1));             // the spin kernel's code object is loaded outside the timed pairs
+    MG_HIP(m, hipStreamSynchronize(l.compute[0]));
+    for (int tries = 0; tries < 3; tries++) {
+        hipStream_t cand = nullptr;
+        MG_HIP(m, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+        MG_HIP(m, hipStreamSynchronize(l.compute[0]));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t e = launch_delay(l.compute[0], spin_us);
+        if (e == hipSuccess) e = launch_delay(cand, spin_us);
+        if (e == hipSuccess) e = hipStreamSynchronize(l.compute[0]);
+        if (e == hipSuccess) e = hipStreamSynchronize(cand);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (e != hipSuccess) { (void)hipStreamDestroy(cand); return hipf(m, e); }
+        if (us < 1.6 * spin_us || tries == 2) {
+            l.compute[1] = cand;
+            l.lanes_overlap = us < 1.6 * spin_us;
+            if (getenv("MIL_DEBUG")) fprintf(stderr, "mil_mg rank %d: second lane stream after %d candidate(s), pair of %u us spins took %.0f us (%s)\n",
+                                             l.rank, tries + 1, spin_us, us, l.lanes_overlap ? "side by side" : "one after the other");
+            return MIL_OK;
+        }
+        (void)hipStreamDestroy(cand);
+    }
+    return MIL_OK;
+}
+
 int create_common(mil_mg *m, const mil_mg_config *cfg)
 {
     for (Local &l : m->locals) {
@@ -188,7 +224,11 @@ int create_common(mil_mg *m, const mil_mg_config *cfg)
         // launch - and 461 with the first chunk on a higher-priority stream beside the second; but with 8 ranks x 3 streams on
         // the 4 hardware queues of this pool (GPU_MAX_HW_QUEUES) mixed-priority streams stopped making progress: all streams
         // here have the default priority.)
-        for (int k = 0; k < l.lanes; k++) MG_HIP(m, hipStreamCreateWithFlags(&l.compute[k], hipStreamNonBlocking));
+        MG_HIP(m, hipStreamCreateWithFlags(&l.compute[0], hipStreamNonBlocking));
+        if (l.lanes > 1) {
+            const int rc = second_lane_stream(m, l);
+            if (rc) return rc;
+        }
         MG_HIP(m, hipStreamCreateWithFlags(&l.gather, hipStreamNonBlocking));
         for (hipEvent_t &e : l.gathered) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const uint32_t n = cfg->chunks ? cfg->chunks : 4u;
