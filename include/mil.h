@@ -368,7 +368,8 @@ int mil_row_weights(const mil_frame_matrix_data *frame, const mil_push_constants
 /* ---- Multi-GPU (SURVEY.md 8 b "Threading", 8 e): strips of one frame / one frame per GPU, gathered to GPU 0. ----
  * No counterpart in the reference, which records the lighting draw for ONE device (render/mod.rs:189-219; the device is
  * picked at render/vulkan.rs:106-108): these calls replace that draw for N devices.  A mil_mg owns, per rank it drives,
- * one mil_ctx, a compute stream, a gather stream and an RCCL communicator.  The pass has no data-path exchange; the only
+ * two shading lanes (a mil_ctx and a compute stream each, taken in turn frame by frame so that one frame's ramp runs under
+ * the previous frame's tail), a gather stream and an RCCL communicator.  The pass has no data-path exchange; the only
  * communication is the gather, grouped ncclSend / ncclRecv to rank 0 (RCCL has no gather primitive), issued per CHUNK of a
  * rank's rows on the gather stream behind an event, so it runs beside the shading of the next chunk.  The assembled frame
  * equals the single-GPU frame bit for bit.  RCCL is bound at run time (dlopen librccl.so.1): MIL_ERR_RCCL if it is missing.
