@@ -1195,6 +1195,7 @@ __global__ __launch_bounds__(256, STAGE ? 4 : 5) void k_tiled(const ShadeParams 
     // kernel were two more spilled into VGPR lanes)
     const uint32_t k_band = (tyi * TILE) >> k_band_shift;
     const RowMap rm_e = { k_y_offset + k_band * k_band_extra, k_band * k_out_band_extra };
+    (void)rm_e;                                         // strict mode has no early store path
     const uint64_t t_start = k_stamps ? __builtin_amdgcn_s_memrealtime() : 0;   // diagnostics only (100 MHz)
 
     // ---- 1. HBM -> LDS, coordinates clamped (not branched) so the loads are straight-line ----
@@ -1295,6 +1296,7 @@ __global__ __launch_bounds__(256, STAGE ? 4 : 5) void k_tiled(const ShadeParams 
     int x0 = 0x7FFFFFFF, x1 = -0x7FFFFFFF, yy0 = 0x7FFFFFFF, yy1 = -0x7FFFFFFF;
     bool lit4[4];
     bool have_pos = false;        // wave-uniform: P - cameraPosition of the tile's pixels is parked in LDS (fast mode)
+    (void)have_pos;
 #pragma unroll
     for (int j = 0; j < 4; j++)   // occlusion 0 => every point-light term is exactly 0
         lit4[j] = xin && (y0 + 4 * j) <= ylast && (s_tex[(4 + j) * 64 + lane] >> 24) != 0;
