@@ -440,6 +440,9 @@ int mil_mg_sync(mil_mg *mg);          /* waits for every local rank's compute an
  * it is called, so that a test can hold the scatter of one frame back while the next frame is already being shaded and sent
  * (the ordering of the staging slices).  Does nothing in a process that does not drive rank 0. */
 int mil_mg_debug_delay_gather(mil_mg *mg, uint32_t microseconds);
+/* The same on the gather streams of the local ranks OTHER than 0 (the senders): a frame's rows then leave a sender's buffer
+ * late, which is what the ordering of the next frame's shading behind them (two lanes per rank) is tested against. */
+int mil_mg_debug_delay_senders(mil_mg *mg, uint32_t microseconds);
 
 int mil_sync(mil_ctx *ctx, void *stream);
 int mil_last_hip_error(const mil_ctx *ctx);

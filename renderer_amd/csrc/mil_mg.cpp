@@ -651,6 +651,17 @@ int mil_mg_debug_delay_gather(mil_mg *m, uint32_t microseconds)
     return MIL_OK;
 }
 
+int mil_mg_debug_delay_senders(mil_mg *m, uint32_t microseconds)
+{
+    if (!m) return MIL_ERR_BAD_ARG;
+    for (Local &l : m->locals)
+        if (l.rank != 0) {
+            MG_HIP(m, hipSetDevice(l.device));
+            MG_HIP(m, launch_delay(l.gather, microseconds));
+        }
+    return MIL_OK;
+}
+
 int mil_mg_sync(mil_mg *m)
 {
     if (!m) return MIL_ERR_BAD_ARG;

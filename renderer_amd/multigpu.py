@@ -24,7 +24,7 @@ UNIQUE_ID_BYTES = 128
 
 EXPORTS = ['mil_mg_create', 'mil_mg_unique_id', 'mil_mg_create_rank', 'mil_mg_destroy', 'mil_mg_world', 'mil_mg_local_ranks',
            'mil_mg_rccl_ranks', 'mil_mg_last_rccl_error', 'mil_mg_last_hip_error', 'mil_mg_rows_of_rank',
-           'mil_mg_frame_rows_of_rank', 'mil_mg_render_strips', 'mil_mg_render_frames', 'mil_mg_sync', 'mil_mg_reserve', 'mil_mg_debug_delay_gather']
+           'mil_mg_frame_rows_of_rank', 'mil_mg_render_strips', 'mil_mg_render_frames', 'mil_mg_sync', 'mil_mg_reserve', 'mil_mg_debug_delay_gather', 'mil_mg_debug_delay_senders']
 
 
 class Config(ctypes.Structure):            # mil_mg_config
@@ -56,6 +56,7 @@ def _lib():
         lib.mil_mg_frame_rows_of_rank.argtypes = [ctypes.POINTER(Config), ci, ci, u32, vp]
         lib.mil_mg_reserve.argtypes = [vp, u32, u32, ci]
         lib.mil_mg_debug_delay_gather.argtypes = [vp, u32]
+        lib.mil_mg_debug_delay_senders.argtypes = [vp, u32]
         lib.mil_mg_render_strips.argtypes = [vp, ctypes.POINTER(RankIO), vp, vp, vp, ci, u32, vp, u32]
         lib.mil_mg_render_frames.argtypes = [vp, ctypes.POINTER(RankIO), vp, vp, vp, ci, u32, ctypes.POINTER(vp), u32]
         _bound = True
@@ -198,6 +199,12 @@ class MultiGpu:
     def reserve(self, width, height, fmt=lighting.OUT_SRGB8):
         """mil_mg_reserve: staging area + every local context's workspace for this frame size, ahead of the frame loop."""
         rc = self.lib.mil_mg_reserve(self.h, width, height, fmt)
+        if rc:
+            self._raise(self.lib, rc, self.h)
+
+    def debug_delay_senders(self, microseconds):
+        """mil_mg_debug_delay_senders (test hook): idles the gather streams of the local ranks other than 0 at this point."""
+        rc = self.lib.mil_mg_debug_delay_senders(self.h, microseconds)
         if rc:
             self._raise(self.lib, rc, self.h)
 

@@ -165,6 +165,54 @@ def test_frames_in_flight_rotating_and_reused_buffers():
         lp.close()
 
 
+@pytest.mark.parametrize('lanes', [2, 1])
+def test_reused_sender_buffers_and_no_sync(lanes):
+    """A rank shades consecutive frames on two lanes (context + stream) in turn, so frame i + 1's launch may start under frame
+    i's tail.  Here every frame has its own lights (each lane's context stages its own), enough of them for the two-kernel
+    form (a workspace per lane), its own destination on rank 0 - and the SENDERS' row buffers are the same for every frame,
+    with no sync in between: frame i + 1's shading must wait until frame i's rows have left the buffer (Local::touched).
+    The senders' gather streams are held back by 1 ms per frame so that a missing wait shows: on a build without it the
+    one-lane run (MIL_MG_LANES=1) gets 6 of 7 frames wrong.  The two-lane run passed on that build too - on one GPU the
+    emulated ranks' dozen streams share four hardware queues, and an event wait of one stream holds back every later packet
+    of its queue - so for two lanes this is the guard that the box allows, not a proof.  Every frame == its monolithic
+    launch, bit for bit."""
+    import os
+    w, h, n = 512, 288, 2
+    cam = synth.sweep_camera(w, h)
+    gb = synth.scene_sweep(w, h, cam, device=DEV)
+    frame = cam.frame_matrix_data()
+    dl = ubo.default_directional_lights()
+    sh = synth.shadow_setup(dl[0, 0:3], 128, device=DEV)
+    lights = [synth.point_light_field(1400 + 100 * (k % 2), 0x5EED0200 + k) for k in range(7)]
+    lp = lighting.LightingPass(0, 4096)
+    want = [lp.light_ex(gb, frame, dl, pl, AMB, sh, fmt=lighting.OUT_SRGB8) for pl in lights]
+    before = os.environ.get('MIL_MG_LANES')
+    os.environ['MIL_MG_LANES'] = str(lanes)          # read by mil_mg_create
+    try:
+        mg = multigpu.MultiGpu.single_process([0] * n, max_point_lights=4096, band_rows=16, chunks=1, transport=multigpu.TRANSPORT_PEER_COPY)
+    finally:
+        if before is None:
+            del os.environ['MIL_MG_LANES']
+        else:
+            os.environ['MIL_MG_LANES'] = before
+    try:
+        rows = [torch.from_numpy(multigpu.frame_rows_of_rank(h, n, r, band_rows=16)).to(DEV) for r in range(n)]
+        parts_gb = [{k: (v[rows[r]].contiguous() if torch.is_tensor(v) else v) for k, v in gb.items()} for r in range(n)]
+        outs = [None if r == 0 else torch.zeros((len(rows[r]), w), dtype=torch.int32, device=DEV) for r in range(n)]
+        fulls = [torch.zeros((h, w), dtype=torch.int32, device=DEV) for _ in lights]
+        mg.reserve(w, h, lighting.OUT_SRGB8)
+        for k, pl in enumerate(lights):
+            mg.debug_delay_senders(1000)
+            parts = [dict(gb=parts_gb[r], point_lights=pl, ambient=AMB, shadow=sh, out=outs[r]) for r in range(n)]
+            mg.render_strips(parts, frame, dl, w, h, fmt=lighting.OUT_SRGB8, full=fulls[k])
+        mg.sync()
+        for k in range(len(lights)):
+            assert torch.equal(fulls[k], want[k]), k
+    finally:
+        mg.close()
+        lp.close()
+
+
 def test_staging_slices_survive_a_held_back_scatter():
     """dealt bands of ranks 1.. travel into staging slices on rank 0's device and are scattered into the frame
     from there; with the peer-copy transport the copies INTO the slices run on the senders' streams, and nothing used to
