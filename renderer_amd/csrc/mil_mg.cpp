@@ -176,32 +176,37 @@ void pieces_in(const std::vector<Piece> &pieces, uint32_t k0, uint32_t k1, std::
 
 size_t bytes_per_px(mil_out_format fmt) { return fmt == MIL_OUT_HDR_RGBA32F ? 16u : 4u; }
 
-// The second lane's stream must not share a hardware queue with the first: HIP deals a process's streams over its hardware
-// queues (GPU_MAX_HW_QUEUES, 4 here) in creation order, and two streams on one queue run their kernels one after the other -
-// the lanes would then buy nothing.  Probe: a 300 us spin kernel (one wave) on the first lane and on a candidate at once; if
-// the pair takes about one spin they run side by side.  Up to three candidates, the rest are destroyed; if none overlaps the
-// last one is kept (correct either way, the order of frames rests on events).  ~1-2 ms once per rank at creation.
-int second_lane_stream(mil_mg *m, Local &l)
+// A rank's streams must not share a hardware queue with one another: HIP deals a process's streams over its hardware queues
+// (GPU_MAX_HW_QUEUES, 4 here) in creation order; two streams on one queue run their kernels one after the other, and an
+// event wait of one of them holds back every later packet of the queue - a second lane would buy nothing there, and a
+// gather stream (whose RCCL kernels wait for their peers) would stall the lane it shares a queue with.  Probe: a 300 us spin
+// kernel (one wave) on every stream of `against` and on a fresh candidate at once; if the lot takes about one spin they run
+// side by side.  Up to four candidates, the rest are destroyed; if none is free of the others the last one is kept (correct
+// either way: the order of frames rests on events).  ~1 ms per stream, once per rank at creation.
+int pick_stream(mil_mg *m, Local &l, hipStream_t *against, int n_against, const char *what, hipStream_t *out, bool *side_by_side)
 {
     const uint32_t spin_us = 300;
-    MG_HIP(m, launch_delay(l.compute[0], 1));             // the spin kernel's code object is loaded outside the timed pairs
-    MG_HIP(m, hipStreamSynchronize(l.compute[0]));
-    for (int tries = 0; tries < 3; tries++) {
+    MG_HIP(m, launch_delay(against[0], 1));               // the spin kernel's code object is loaded outside the timed runs
+    MG_HIP(m, hipStreamSynchronize(against[0]));
+    const int max_tries = 4;
+    for (int tries = 0; tries < max_tries; tries++) {
         hipStream_t cand = nullptr;
         MG_HIP(m, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
-        MG_HIP(m, hipStreamSynchronize(l.compute[0]));
+        for (int k = 0; k < n_against; k++) MG_HIP(m, hipStreamSynchronize(against[k]));
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t e = launch_delay(l.compute[0], spin_us);
+        hipError_t e = hipSuccess;
+        for (int k = 0; k < n_against && e == hipSuccess; k++) e = launch_delay(against[k], spin_us);
         if (e == hipSuccess) e = launch_delay(cand, spin_us);
-        if (e == hipSuccess) e = hipStreamSynchronize(l.compute[0]);
+        for (int k = 0; k < n_against && e == hipSuccess; k++) e = hipStreamSynchronize(against[k]);
         if (e == hipSuccess) e = hipStreamSynchronize(cand);
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         if (e != hipSuccess) { (void)hipStreamDestroy(cand); return hipf(m, e); }
-        if (us < 1.6 * spin_us || tries == 2) {
-            l.compute[1] = cand;
-            l.lanes_overlap = us < 1.6 * spin_us;
-            if (getenv("MIL_DEBUG")) fprintf(stderr, "mil_mg rank %d: second lane stream after %d candidate(s), pair of %u us spins took %.0f us (%s)\n",
-                                             l.rank, tries + 1, spin_us, us, l.lanes_overlap ? "side by side" : "one after the other");
+        const bool ok = us < 1.6 * spin_us;
+        if (ok || tries == max_tries - 1) {
+            *out = cand;
+            *side_by_side = ok;
+            if (getenv("MIL_DEBUG")) fprintf(stderr, "mil_mg rank %d: %s stream after %d candidate(s), %d spins of %u us took %.0f us (%s)\n",
+                                             l.rank, what, tries + 1, n_against + 1, spin_us, us, ok ? "side by side" : "one after the other");
             return MIL_OK;
         }
         (void)hipStreamDestroy(cand);
@@ -226,10 +231,14 @@ int create_common(mil_mg *m, const mil_mg_config *cfg)
         // here have the default priority.)
         MG_HIP(m, hipStreamCreateWithFlags(&l.compute[0], hipStreamNonBlocking));
         if (l.lanes > 1) {
-            const int rc = second_lane_stream(m, l);
+            const int rc = pick_stream(m, l, l.compute, 1, "second lane", &l.compute[1], &l.lanes_overlap);
             if (rc) return rc;
         }
-        MG_HIP(m, hipStreamCreateWithFlags(&l.gather, hipStreamNonBlocking));
+        {
+            bool free_of_lanes = false;
+            const int rc = pick_stream(m, l, l.compute, l.lanes, "gather", &l.gather, &free_of_lanes);
+            if (rc) return rc;
+        }
         for (hipEvent_t &e : l.gathered) MG_HIP(m, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const uint32_t n = cfg->chunks ? cfg->chunks : 4u;
         l.chunk_done.resize(n + 1);
